@@ -1,0 +1,225 @@
+/*
+ * rayzen_hip.h -- C-ABI of the MI355X (gfx950) path-tracing render loop.
+ *
+ * This is the drop-in boundary for RayZen's render hot path.  RayZen (the
+ * reference, cited as file:line relative to /root/reference/RayZen) has no
+ * FFI of its own for this path: its frontend talks to the GPU through raw
+ * OpenGL calls.  Every entry point below replaces one group of those calls,
+ * and every struct is byte-for-byte the element type of one of RayZen's
+ * SSBOs (C++ layout == std430 layout), so a frontend hands over the very
+ * same std::vector<T>::data() pointers it gives to glBufferData today.
+ *
+ * Plain C, plain pointers and sizes.  No C++ exception crosses this ABI:
+ * every call returns RZ_OK (0) or a negative rz_status and records a message
+ * readable through rz_last_error().  A context is externally synchronised
+ * (one thread at a time), like the single GL context of the reference.
+ */
+#ifndef RAYZEN_HIP_H
+#define RAYZEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* SSBO element types (the data contract).                                   */
+/* ------------------------------------------------------------------------ */
+
+/* include/Mesh.h:9-17, shaders/fragment_shader.glsl:30-38.  64 B, align 16.
+ * Vertices are in OBJECT space (src/main.cpp:971-972). */
+typedef struct rz_triangle {
+    float v0[3]; float pad0;
+    float v1[3]; float pad1;
+    float v2[3]; float pad2;
+    int32_t materialIndex;
+    int32_t tail_pad[3];
+} rz_triangle;
+
+/* include/BVH.h:7-12, fragment_shader.glsl:40-45.  32 B.
+ * internal: count == -1, children at leftFirst and leftFirst+1;
+ * leaf:     count in [1,4] (0 for an empty mesh), leftFirst = first slot in
+ *           the index array (src/BVH.cpp:115-118,166-171). */
+typedef struct rz_bvh_node {
+    float boundsMin[3]; int32_t leftFirst;
+    float boundsMax[3]; int32_t count;
+} rz_bvh_node;
+
+/* include/BVH.h:14-21, fragment_shader.glsl:86-93.  144 B.
+ * mat4 are column-major (GLM / GLSL convention). */
+typedef struct rz_bvh_instance {
+    int32_t blasNodeOffset;
+    int32_t blasTriOffset;
+    int32_t meshIndex;
+    int32_t globalTriOffset;
+    float   transform[16];
+    float   inverseTransform[16];
+} rz_bvh_instance;
+
+/* include/Material.h:6-18, fragment_shader.glsl:15-22.  32 B. */
+typedef struct rz_material {
+    float albedo[3];
+    float metallic;
+    float roughness;
+    float reflectivity;
+    float transparency;
+    float ior;
+} rz_material;
+
+/* include/Light.h:6-13, fragment_shader.glsl:24-28.  32 B.
+ * positionOrDirection.w == 1 -> point light, otherwise directional. */
+typedef struct rz_light {
+    float positionOrDirection[4];
+    float color[3];
+    float power;
+} rz_light;
+
+/* Binding points: the numeric values ARE the GL SSBO binding indices of the
+ * reference (fragment_shader.glsl:47-96, src/main.cpp:1072-1119).  Bindings
+ * 3 and 4 are dead in the reference and do not exist here. */
+typedef enum rz_binding {
+    RZ_BIND_TRIANGLES    = 0,  /* rz_triangle[]      */
+    RZ_BIND_MATERIALS    = 1,  /* rz_material[]      */
+    RZ_BIND_LIGHTS       = 2,  /* rz_light[]         */
+    RZ_BIND_TLAS_NODES   = 5,  /* rz_bvh_node[]      */
+    RZ_BIND_TLAS_INDICES = 6,  /* int32[] instance ids */
+    RZ_BIND_BLAS_NODES   = 7,  /* rz_bvh_node[] (all meshes concatenated) */
+    RZ_BIND_BLAS_INDICES = 8,  /* int32[] mesh-local triangle ids */
+    RZ_BIND_INSTANCES    = 9   /* rz_bvh_instance[]  */
+} rz_binding;
+
+typedef enum rz_status {
+    RZ_OK                 =  0,
+    RZ_ERR_INVALID_ARG    = -1,
+    RZ_ERR_NO_DEVICE      = -2,
+    RZ_ERR_HIP            = -3,  /* a HIP runtime call failed */
+    RZ_ERR_OUT_OF_RANGE   = -4,  /* rz_update past the end of a binding */
+    RZ_ERR_NOT_READY      = -5,  /* render before all bindings / frame set */
+    RZ_ERR_BAD_SCENE      = -6,  /* uploaded arrays are inconsistent */
+    RZ_ERR_BUFFER_SIZE    = -7   /* caller buffer too small */
+} rz_status;
+
+/* Per-frame parameters = the uniforms of sendSceneDataToShader
+ * (src/main.cpp:1356-1379; fragment_shader.glsl:4-13,100,105) plus the three
+ * knobs the reference hard-codes (spp: `numSamples = 1`, fragment_shader.glsl:675)
+ * or does not have (sample_base, tile sharding).  Matrices are column-major.
+ * The traced radiance reads only inv_view, inv_proj and cam_pos
+ * (fragment_shader.glsl:208-211,714); view/proj ride along for the
+ * resolve/overlay stage. */
+typedef struct rz_frame_params {
+    int32_t width, height;      /* `resolution` */
+    float   inv_view[16];
+    float   inv_proj[16];
+    float   view[16];
+    float   proj[16];
+    float   cam_pos[3];
+    int32_t num_lights;         /* `numLights` */
+    int32_t bounce_budget;      /* `uniformBounceBudget`; <= 0 means 5 (glsl:673) */
+    int32_t spp;                /* samples per pixel rendered by one rz_render */
+    int32_t sample_base;        /* first sample index; 0 resets per-pixel state */
+    int32_t tile_rank;          /* this context renders tiles t with          */
+    int32_t tile_nranks;        /*   t % tile_nranks == tile_rank (1 => all)  */
+} rz_frame_params;
+
+#define RZ_TILE_W 8             /* pixel tile = one wavefront: 8 x 8 pixels */
+#define RZ_TILE_H 8
+
+/* Counters of the REFERENCE algorithm's memory touches (what the fragment
+ * shader would read from its SSBOs), used to price the roofline. Filled by
+ * rz_render_counted().  bytes = 32*tlas_nodes + 4*tlas_leaf_indices +
+ * 144*instances + 32*blas_nodes + 68*triangles + 32*materials +
+ * 32*light_fetches + 16*pixels  (SURVEY.md section 8d). */
+typedef struct rz_counters {
+    uint64_t samples;           /* camera paths started                      */
+    uint64_t traversals;        /* traverseTLAS calls (primary+shadow+bounce) */
+    uint64_t tlas_nodes;        /* tlasNodes[] elements popped               */
+    uint64_t tlas_leaf_indices; /* tlasTriIndices[] elements read            */
+    uint64_t instances;         /* bvhInstances[] elements entered           */
+    uint64_t blas_nodes;        /* blasNodes[] elements popped               */
+    uint64_t triangles;         /* hitTriangle calls (index + triangle read) */
+    uint64_t materials;         /* materials[] fetches                       */
+    uint64_t light_fetches;     /* lights[] fetches                          */
+    uint64_t pixels;            /* accumulation-buffer pixels written        */
+} rz_counters;
+
+typedef struct rz_ctx rz_ctx;
+
+/* glfwCreateWindow/MakeContextCurrent (main.cpp:228-241) / teardown (681-686).
+ * device = HIP device ordinal.  flags: RZ_FLAG_* below.  Returns NULL on
+ * failure (query rz_last_error(NULL)). */
+#define RZ_FLAG_NONE          0u
+#define RZ_FLAG_MEGAKERNEL    1u  /* force the one-thread-per-pixel kernel  */
+#define RZ_FLAG_WAVEFRONT     2u  /* force the queued wavefront pipeline    */
+rz_ctx*     rz_create(int device, unsigned flags);
+void        rz_destroy(rz_ctx* ctx);
+const char* rz_last_error(const rz_ctx* ctx);
+
+/* glGenBuffers + glBufferData + glBindBufferBase (main.cpp:1072-1119).
+ * Allocates device storage for the binding and copies `bytes` from host
+ * memory; the host pointer is not retained. `bytes` must be a multiple of
+ * the binding's element size; 0 is allowed (empty binding). */
+int rz_upload(rz_ctx* ctx, rz_binding binding, const void* data, size_t bytes);
+
+/* glBufferSubData (main.cpp:1196-1207): in-place refresh of
+ * [offset, offset+bytes) of a binding uploaded before. */
+int rz_update(rz_ctx* ctx, rz_binding binding, size_t offset,
+              const void* data, size_t bytes);
+
+/* glUniform* in sendSceneDataToShader (main.cpp:1356-1379). */
+int rz_set_frame(rz_ctx* ctx, const rz_frame_params* params);
+
+/* Optional plumbing for a caller that owns the device memory and the stream
+ * (e.g. a torch tensor reduced with RCCL): render on `hip_stream` (a
+ * hipStream_t; NULL = the context's own stream) and accumulate into
+ * `device_rgba` (width*height*4 floats, device memory; NULL = the context's
+ * own buffer). */
+int rz_set_stream(rz_ctx* ctx, void* hip_stream);
+int rz_bind_accum(rz_ctx* ctx, void* device_rgba, size_t bytes);
+
+/* glDrawArrays(GL_TRIANGLE_FAN,0,4) (main.cpp:637): asynchronous launch of
+ * one path-tracing frame: params.spp samples for every pixel of the tiles
+ * this context owns, ADDED to the accumulation buffer (RGBA32F; rgb = sum of
+ * per-sample radiance before the reference's divide and clamp,
+ * fragment_shader.glsl:772-773; a = number of samples).  sample_base == 0
+ * first clears the owned pixels. */
+int rz_render(rz_ctx* ctx);
+/* Same frame, and additionally counts the reference algorithm's memory
+ * touches (slower; never used for timing). */
+int rz_render_counted(rz_ctx* ctx, rz_counters* out);
+/* glFinish (main.cpp:1347). */
+int rz_sync(rz_ctx* ctx);
+
+/* Zero the whole accumulation buffer (all pixels, owned or not). */
+int rz_clear_accum(rz_ctx* ctx);
+
+/* The reference never reads pixels back; this is new.  Copies the RGBA32F
+ * accumulation buffer to host.  Row 0 is the BOTTOM row (gl_FragCoord
+ * origin).  Synchronises. */
+int rz_read_accum(rz_ctx* ctx, float* rgba, size_t bytes);
+
+/* color /= numSamples; clamp(0,1) (fragment_shader.glsl:772-773), then
+ * 8-bit quantisation round(c*255) as the default framebuffer would.
+ * Row 0 = bottom row.  Synchronises. */
+int rz_resolve_rgba8(rz_ctx* ctx, uint8_t* rgba8, size_t bytes);
+
+/* Wall-clock-free timing: milliseconds the render kernels of the LAST
+ * rz_render spent on the GPU (HIP events on the stream they ran on), and how
+ * many kernel launches that was.  Synchronises. */
+int rz_last_render_ms(rz_ctx* ctx, float* ms, int* launches);
+
+/* Device pointer of the accumulation buffer currently in use. */
+void* rz_accum_device_ptr(rz_ctx* ctx);
+
+/* Library/version probe that needs no GPU. */
+const char* rz_version(void);
+/* sizeof() of the ABI structs as compiled into the library, for layout
+ * checks from other languages: which = 0 triangle, 1 node, 2 instance,
+ * 3 material, 4 light, 5 frame_params, 6 counters. */
+size_t rz_sizeof(int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYZEN_HIP_H */

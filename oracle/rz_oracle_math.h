@@ -1,0 +1,141 @@
+/*
+ * rz_oracle_math.h -- the pinned definitions of the GLSL built-ins used by
+ * RayZen's path tracer (shaders/fragment_shader.glsl, "FS").
+ *
+ * TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may use anything under oracle/.  PARITY UNPINNED: the
+ * reference has no tests or golden vectors for this path and its renderer
+ * cannot run here (no GL context, no GLM); GLSL leaves the precision of
+ * sin/cos/acos/pow/normalize to the driver.  The definitions below ARE the
+ * specification both this oracle and the HIP kernels implement.
+ *
+ * Rules (SURVEY.md section 8a "numerics"):
+ *   - all scene arithmetic is IEEE binary32, one rounding per operation,
+ *     evaluated left to right, NO fused multiply-add (compile with
+ *     -ffp-contract=off);
+ *   - division and sqrt are correctly rounded;
+ *   - min/max are IEEE-754 minNum/maxNum (the non-NaN operand wins), which
+ *     is what GPU min/max instructions do;
+ *   - sin/cos/acos are computed in binary64 from + - * / sqrt fma floor rint
+ *     only (all exactly specified by IEEE-754, hence bit-identical on any
+ *     conforming CPU or GPU) and rounded once to binary32.  The polynomial
+ *     coefficients are the published fdlibm (FreeBSD msun k_sin.c, k_cos.c,
+ *     e_acos.c) minimax coefficients; the argument reduction is a 3-term
+ *     Cody-Waite split of pi/2 applied with fma.
+ */
+#ifndef RZ_ORACLE_MATH_H
+#define RZ_ORACLE_MATH_H
+
+#include <math.h>
+
+static inline float rzo_min(float a, float b) {     /* minNum */
+    if (a != a) return b;
+    if (b != b) return a;
+    return (b < a) ? b : a;
+}
+static inline float rzo_max(float a, float b) {     /* maxNum */
+    if (a != a) return b;
+    if (b != b) return a;
+    return (a < b) ? b : a;
+}
+static inline float rzo_clamp(float x, float lo, float hi) {
+    return rzo_min(rzo_max(x, lo), hi);
+}
+static inline float rzo_mix(float a, float b, float t) {
+    return a * (1.0f - t) + b * t;
+}
+static inline float rzo_fract(float x) { return x - floorf(x); }
+static inline float rzo_pow2(float x) { return x * x; }
+static inline float rzo_pow5(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x; }
+
+/* x -> (r, quadrant): r = x - k*pi/2, k = rint(x*2/pi), quadrant = k mod 4. */
+static inline double rzo_reduce_pio2(double x, int* quadrant) {
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double P1 = 1.57079632673412561417e+00;   /* first 33 bits of pi/2 */
+    const double P2 = 6.07710050630396597660e-11;   /* next 33 bits */
+    const double P3 = 2.02226624871116645580e-21;   /* next 33 bits */
+    double k = __builtin_rint(x * TWO_OVER_PI);
+    double r = __builtin_fma(-k, P1, x);
+    r = __builtin_fma(-k, P2, r);
+    r = __builtin_fma(-k, P3, r);
+    double q = k - 4.0 * __builtin_floor(k * 0.25);  /* exact, in {0,1,2,3} */
+    *quadrant = (int)q;
+    return r;
+}
+static inline double rzo_ksin(double r) {           /* |r| <= pi/4 (+slack) */
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double z = r * r;
+    double p = __builtin_fma(z, S6, S5);
+    p = __builtin_fma(z, p, S4);
+    p = __builtin_fma(z, p, S3);
+    p = __builtin_fma(z, p, S2);
+    p = __builtin_fma(z, p, S1);
+    return __builtin_fma(z * r, p, r);
+}
+static inline double rzo_kcos(double r) {
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = r * r;
+    double p = __builtin_fma(z, C6, C5);
+    p = __builtin_fma(z, p, C4);
+    p = __builtin_fma(z, p, C3);
+    p = __builtin_fma(z, p, C2);
+    p = __builtin_fma(z, p, C1);
+    double h = __builtin_fma(z, -0.5, 1.0);
+    return __builtin_fma(z * z, p, h);
+}
+static inline float rzo_sin(float x) {
+    int q; double r = rzo_reduce_pio2((double)x, &q);
+    double s = rzo_ksin(r), c = rzo_kcos(r);
+    double v = (q & 1) ? c : s;
+    if (q & 2) v = -v;
+    return (float)v;
+}
+static inline float rzo_cos(float x) {
+    int q; double r = rzo_reduce_pio2((double)x, &q);
+    double s = rzo_ksin(r), c = rzo_kcos(r);
+    double v = (q & 1) ? s : c;
+    if (((q + 1) & 2) != 0) v = -v;
+    return (float)v;
+}
+static inline float rzo_acos(float xf) {
+    const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01,
+                 pS2 = 2.01212532134862925881e-01, pS3 = -4.00555345006794114027e-02,
+                 pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+                 qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00,
+                 qS3 = -6.88283971605453293030e-01, qS4 = 7.70381505559019352791e-02;
+    const double PIO2 = 1.57079632679489655800e+00, PI = 3.14159265358979311600e+00;
+    double x = (double)xf;
+    double ax = (x < 0.0) ? -x : x;
+    if (!(ax < 1.0)) {                       /* |x| >= 1 or NaN */
+        if (x != x) return xf;
+        return (x > 0.0) ? 0.0f : (float)PI;
+    }
+    int small = ax < 0.5;
+    double z = small ? x * x : (1.0 - ax) * 0.5;
+    double p = __builtin_fma(z, pS5, pS4);
+    p = __builtin_fma(z, p, pS3);
+    p = __builtin_fma(z, p, pS2);
+    p = __builtin_fma(z, p, pS1);
+    p = __builtin_fma(z, p, pS0);
+    p = p * z;
+    double qd = __builtin_fma(z, qS4, qS3);
+    qd = __builtin_fma(z, qd, qS2);
+    qd = __builtin_fma(z, qd, qS1);
+    qd = __builtin_fma(z, qd, 1.0);
+    double R = p / qd;
+    double res;
+    if (small) {
+        res = PIO2 - __builtin_fma(x, R, x);
+    } else {
+        double s = __builtin_sqrt(z);
+        double t = 2.0 * __builtin_fma(s, R, s);
+        res = (x > 0.0) ? t : PI - t;
+    }
+    return (float)res;
+}
+
+#endif

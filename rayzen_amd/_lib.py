@@ -1,0 +1,115 @@
+"""ctypes loaders for the in-tree shared libraries.
+
+There is no CPU fallback for rendering: if librayzen_hip.so is missing or has
+no GPU to talk to, the calls fail loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_SO = os.path.join(_HERE, "lib", "librayzen_hip.so")
+HOST_SO = os.path.join(_HERE, "lib", "librayzen_host.so")
+
+# the symbols include/rayzen_hip.h declares
+HIP_SYMBOLS = (
+    "rz_create", "rz_destroy", "rz_last_error", "rz_upload", "rz_update", "rz_set_frame", "rz_set_stream",
+    "rz_bind_accum", "rz_render", "rz_render_counted", "rz_sync", "rz_clear_accum", "rz_read_accum",
+    "rz_resolve_rgba8", "rz_last_render_ms", "rz_accum_device_ptr", "rz_version", "rz_sizeof",
+)
+# the symbols include/rayzen_host.h declares
+HOST_SYMBOLS = (
+    "rzh_load_obj", "rzh_build_blas", "rzh_build_tlas", "rzh_world_bounds", "rzh_scene_create",
+    "rzh_scene_destroy", "rzh_scene_add_mesh", "rzh_scene_add_object", "rzh_scene_set_transform",
+    "rzh_scene_build", "rzh_scene_update_dynamic", "rzh_scene_buffer", "rzh_scene_depths",
+    "rzh_camera_matrices", "rzh_mat_translate", "rzh_mat_scale", "rzh_mat_rotate", "rzh_mat_inverse",
+    "rzh_make_cube", "rzh_make_blob", "rzh_version",
+)
+
+
+class FrameParams(C.Structure):
+    """rz_frame_params of include/rayzen_hip.h."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32),
+                ("inv_view", C.c_float * 16), ("inv_proj", C.c_float * 16),
+                ("view", C.c_float * 16), ("proj", C.c_float * 16),
+                ("cam_pos", C.c_float * 3),
+                ("num_lights", C.c_int32), ("bounce_budget", C.c_int32),
+                ("spp", C.c_int32), ("sample_base", C.c_int32),
+                ("tile_rank", C.c_int32), ("tile_nranks", C.c_int32)]
+
+
+COUNTER_FIELDS = ("samples", "traversals", "tlas_nodes", "tlas_leaf_indices", "instances",
+                  "blas_nodes", "triangles", "materials", "light_fetches", "pixels")
+
+
+class Counters(C.Structure):
+    """rz_counters of include/rayzen_hip.h."""
+    _fields_ = [(n, C.c_uint64) for n in COUNTER_FIELDS]
+
+
+_hip = None
+_host = None
+
+
+def hip():
+    """librayzen_hip.so with prototypes set.  Raises if it has not been built."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_SO):
+            raise RuntimeError(f"{HIP_SO} is missing: run `python -m rayzen_amd.build` (needs hipcc). "
+                               "There is no CPU fallback for the render path.")
+        L = C.CDLL(HIP_SO)
+        vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+        L.rz_create.restype, L.rz_create.argtypes = vp, [i, C.c_uint]
+        L.rz_destroy.restype, L.rz_destroy.argtypes = None, [vp]
+        L.rz_last_error.restype, L.rz_last_error.argtypes = C.c_char_p, [vp]
+        L.rz_upload.restype, L.rz_upload.argtypes = i, [vp, i, vp, sz]
+        L.rz_update.restype, L.rz_update.argtypes = i, [vp, i, sz, vp, sz]
+        L.rz_set_frame.restype, L.rz_set_frame.argtypes = i, [vp, C.POINTER(FrameParams)]
+        L.rz_set_stream.restype, L.rz_set_stream.argtypes = i, [vp, vp]
+        L.rz_bind_accum.restype, L.rz_bind_accum.argtypes = i, [vp, vp, sz]
+        L.rz_render.restype, L.rz_render.argtypes = i, [vp]
+        L.rz_render_counted.restype, L.rz_render_counted.argtypes = i, [vp, C.POINTER(Counters)]
+        L.rz_sync.restype, L.rz_sync.argtypes = i, [vp]
+        L.rz_clear_accum.restype, L.rz_clear_accum.argtypes = i, [vp]
+        L.rz_read_accum.restype, L.rz_read_accum.argtypes = i, [vp, vp, sz]
+        L.rz_resolve_rgba8.restype, L.rz_resolve_rgba8.argtypes = i, [vp, vp, sz]
+        L.rz_last_render_ms.restype, L.rz_last_render_ms.argtypes = i, [vp, C.POINTER(C.c_float), C.POINTER(i)]
+        L.rz_accum_device_ptr.restype, L.rz_accum_device_ptr.argtypes = vp, [vp]
+        L.rz_version.restype, L.rz_version.argtypes = C.c_char_p, []
+        L.rz_sizeof.restype, L.rz_sizeof.argtypes = sz, [i]
+        _hip = L
+    return _hip
+
+
+def host():
+    """librayzen_host.so with prototypes set."""
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_SO):
+            raise RuntimeError(f"{HOST_SO} is missing: run `python -m rayzen_amd.build`")
+        L = C.CDLL(HOST_SO)
+        vp, i, sz, f = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+        L.rzh_load_obj.restype, L.rzh_load_obj.argtypes = i, [C.c_char_p, i, vp, i]
+        L.rzh_build_blas.restype, L.rzh_build_blas.argtypes = i, [vp, i, vp, vp, C.POINTER(i)]
+        L.rzh_build_tlas.restype, L.rzh_build_tlas.argtypes = i, [vp, i, vp, vp, C.POINTER(i)]
+        L.rzh_world_bounds.restype, L.rzh_world_bounds.argtypes = None, [vp, vp, vp, vp]
+        L.rzh_scene_create.restype, L.rzh_scene_create.argtypes = vp, []
+        L.rzh_scene_destroy.restype, L.rzh_scene_destroy.argtypes = None, [vp]
+        L.rzh_scene_add_mesh.restype, L.rzh_scene_add_mesh.argtypes = i, [vp, vp, i]
+        L.rzh_scene_add_object.restype, L.rzh_scene_add_object.argtypes = i, [vp, i, vp]
+        L.rzh_scene_set_transform.restype, L.rzh_scene_set_transform.argtypes = i, [vp, i, vp]
+        L.rzh_scene_build.restype, L.rzh_scene_build.argtypes = i, [vp, i]
+        L.rzh_scene_update_dynamic.restype, L.rzh_scene_update_dynamic.argtypes = i, [vp]
+        L.rzh_scene_buffer.restype, L.rzh_scene_buffer.argtypes = vp, [vp, i, C.POINTER(sz)]
+        L.rzh_scene_depths.restype, L.rzh_scene_depths.argtypes = None, [vp, C.POINTER(i), C.POINTER(i)]
+        L.rzh_camera_matrices.restype = None
+        L.rzh_camera_matrices.argtypes = [vp, vp, vp, f, f, f, f, vp, vp, vp, vp]
+        for n in ("rzh_mat_translate", "rzh_mat_scale"):
+            getattr(L, n).restype, getattr(L, n).argtypes = None, [vp, vp, vp]
+        L.rzh_mat_rotate.restype, L.rzh_mat_rotate.argtypes = None, [vp, f, vp, vp]
+        L.rzh_mat_inverse.restype, L.rzh_mat_inverse.argtypes = None, [vp, vp]
+        L.rzh_make_cube.restype, L.rzh_make_cube.argtypes = i, [i, vp, i]
+        L.rzh_make_blob.restype, L.rzh_make_blob.argtypes = i, [i, f, C.c_uint, i, vp, i]
+        L.rzh_version.restype, L.rzh_version.argtypes = C.c_char_p, []
+        _host = L
+    return _host

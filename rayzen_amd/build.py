@@ -1,0 +1,81 @@
+"""Builds the two in-tree shared libraries of the product:
+
+  rayzen_amd/lib/librayzen_hip.so   HIP kernels + the C-ABI of include/rayzen_hip.h
+                                    (hipcc, --offload-arch=gfx950, cross-compiles without a GPU)
+  rayzen_amd/lib/librayzen_host.so  host-side scene / BVH builders, include/rayzen_host.h (g++)
+
+`python -m rayzen_amd.build` or rayzen_amd.build.build_all().  Both land in
+the source tree so they travel to the GPU box with the repository snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "rayzen_amd")
+LIB = os.path.join(PKG, "lib")
+INC = os.path.join(ROOT, "include")
+HIP_DIR = os.path.join(PKG, "csrc", "hip")
+HOST_DIR = os.path.join(PKG, "csrc", "host")
+
+HIP_SO = os.path.join(LIB, "librayzen_hip.so")
+HOST_SO = os.path.join(LIB, "librayzen_host.so")
+
+# -ffp-contract=off is part of the numerics contract (rz_device_math.h), not a tuning flag.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+               "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _files(d, exts):
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts))
+
+
+def hipcc_path():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def build_hip(force=False, verbose=False, extra_flags=()):
+    os.makedirs(LIB, exist_ok=True)
+    srcs = _files(HIP_DIR, (".hip",))
+    deps = srcs + _files(HIP_DIR, (".h",)) + _files(INC, (".h",)) + [os.path.abspath(__file__)]
+    if not force and not _newer(HIP_SO, deps):
+        return HIP_SO
+    cmd = [hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + ["-I", INC, "-I", HIP_DIR, "-shared", "-o", HIP_SO] + srcs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return HIP_SO
+
+
+def build_host(force=False, verbose=False):
+    os.makedirs(LIB, exist_ok=True)
+    srcs = _files(HOST_DIR, (".cpp",))
+    deps = srcs + _files(HOST_DIR, (".h",)) + _files(INC, (".h",)) + [os.path.abspath(__file__)]
+    if not force and not _newer(HOST_SO, deps):
+        return HOST_SO
+    cmd = [os.environ.get("CXX", "g++")] + CXX_FLAGS + ["-I", INC, "-I", HOST_DIR, "-shared", "-o", HOST_SO] + srcs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return HOST_SO
+
+
+def build_all(force=False, verbose=False):
+    return build_host(force, verbose), build_hip(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)
+    print("built", HOST_SO, HIP_SO)

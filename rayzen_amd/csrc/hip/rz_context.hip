@@ -1,0 +1,606 @@
+// rz_context.hip -- the C-ABI of include/rayzen_hip.h: context, uploads, the
+// one-time re-layout of RayZen's SSBO arrays into the device structures of
+// rz_scene_dev.h, launches and read-back.  Host code, compiled by hipcc.
+//
+// Replaces, call for call, what RayZen/src/main.cpp does with OpenGL:
+//   rz_upload     <- glGenBuffers+glBufferData+glBindBufferBase (main.cpp:1072-1119)
+//   rz_update     <- glBufferSubData                            (main.cpp:1196-1207)
+//   rz_set_frame  <- glUniform* in sendSceneDataToShader        (main.cpp:1356-1379)
+//   rz_render     <- glDrawArrays(GL_TRIANGLE_FAN,0,4)          (main.cpp:637)
+//   rz_sync       <- glFinish                                   (main.cpp:1347)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "rayzen_hip.h"
+#include "rz_scene_dev.h"
+
+namespace rz {
+void launch_render_pixels(const KParams& K, bool counted, hipStream_t stream);
+void launch_resolve(const float4* accum, uchar4* out, int n, hipStream_t stream);
+}  // namespace rz
+
+using namespace rz;
+
+namespace {
+
+thread_local std::string g_last_error = "";
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// One BLAS as seen from an instance: RayZen lets every instance name its own
+// node / index / triangle offsets (include/BVH.h:14-21); distinct triples are
+// laid out once each.
+struct BlasView {
+    int pairBase = 0, triBase = 0;
+    int rootEnc = 0;
+    float rootMin[3] = {0, 0, 0}, rootMax[3] = {0, 0, 0};
+    int depth = 1;
+    bool empty = false;
+};
+
+constexpr int kNumBindings = 10;
+size_t elem_size(int b) {
+    switch (b) {
+        case RZ_BIND_TRIANGLES: return sizeof(rz_triangle);
+        case RZ_BIND_MATERIALS: return sizeof(rz_material);
+        case RZ_BIND_LIGHTS: return sizeof(rz_light);
+        case RZ_BIND_TLAS_NODES: return sizeof(rz_bvh_node);
+        case RZ_BIND_TLAS_INDICES: return sizeof(int32_t);
+        case RZ_BIND_BLAS_NODES: return sizeof(rz_bvh_node);
+        case RZ_BIND_BLAS_INDICES: return sizeof(int32_t);
+        case RZ_BIND_INSTANCES: return sizeof(rz_bvh_instance);
+        default: return 0;
+    }
+}
+
+}  // namespace
+
+struct rz_ctx {
+    int device = 0;
+    unsigned flags = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    bool timed = false;
+    int lastLaunches = 0;
+    std::string err;
+
+    // host copies of the caller's arrays (the re-layout needs them; rz_update patches them)
+    std::vector<unsigned char> host[kNumBindings];
+    bool present[kNumBindings] = {};
+    bool geomDirty = true, instDirty = true, tlasDirty = true, matDirty = true, lightDirty = true;
+
+    // device scene
+    DevBuf dPairs, dTris, dInst, dTlasNodes, dTlasIdx, dMat, dLight, dCounters, dResolve;
+    std::map<std::tuple<int, int, int>, BlasView> views;
+    std::vector<DevPair> hPairs;
+    std::vector<DevTri> hTris;
+    int maxBlasDepth = 1, tlasDepth = 1;
+
+    // frame
+    bool haveFrame = false;
+    rz_frame_params frame{};
+    DevBuf ownAccum, dIor;
+    void* extAccum = nullptr;
+    size_t extAccumBytes = 0;
+};
+
+namespace {
+
+int fail(rz_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    g_last_error = buf;
+    return code;
+}
+
+#define RZ_HIP(c, call)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) return fail((c), RZ_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+int ensure(rz_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return RZ_OK;
+    b.release();
+    size_t want = std::max<size_t>(bytes, 256);
+    RZ_HIP(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return RZ_OK;
+}
+
+int upload_vec(rz_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+    int rc = ensure(c, b, bytes);
+    if (rc != RZ_OK) return rc;
+    if (bytes) RZ_HIP(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return RZ_OK;
+}
+
+template <class T> const T* hostArr(const rz_ctx* c, int b) { return reinterpret_cast<const T*>(c->host[b].data()); }
+template <class T> size_t hostCount(const rz_ctx* c, int b) { return c->host[b].size() / sizeof(T); }
+
+// Lay out one BLAS: breadth-first walk from its root, one DevPair per internal
+// node (so the hot top levels are contiguous), triangles gathered to leaf order.
+int build_view(rz_ctx* c, int nodeOff, int triOff, int gTriOff, BlasView& V) {
+    const rz_bvh_node* nodes = hostArr<rz_bvh_node>(c, RZ_BIND_BLAS_NODES);
+    const int32_t* idx = hostArr<int32_t>(c, RZ_BIND_BLAS_INDICES);
+    const rz_triangle* tris = hostArr<rz_triangle>(c, RZ_BIND_TRIANGLES);
+    const long long nNodes = (long long)hostCount<rz_bvh_node>(c, RZ_BIND_BLAS_NODES);
+    const long long nIdx = (long long)hostCount<int32_t>(c, RZ_BIND_BLAS_INDICES);
+    const long long nTris = (long long)hostCount<rz_triangle>(c, RZ_BIND_TRIANGLES);
+    if (nodeOff < 0 || nodeOff >= nNodes) return fail(c, RZ_ERR_BAD_SCENE, "instance blasNodeOffset %d outside the BLAS node array (%lld)", nodeOff, nNodes);
+    V.pairBase = (int)c->hPairs.size();
+    V.triBase = (int)c->hTris.size();
+    const rz_bvh_node& root = nodes[nodeOff];
+    std::memcpy(V.rootMin, root.boundsMin, 12);
+    std::memcpy(V.rootMax, root.boundsMax, 12);
+
+    // slot s of this view's leaf-ordered triangle range <-> blasTriIndices[triOff + s]
+    auto leafEnc = [&](const rz_bvh_node& n, int& enc) -> int {
+        if (n.count > 15) return fail(c, RZ_ERR_BAD_SCENE, "BLAS leaf with %d triangles (max 15)", n.count);
+        if (n.leftFirst < 0 || (long long)triOff + n.leftFirst + n.count > nIdx || triOff < 0)
+            return fail(c, RZ_ERR_BAD_SCENE, "BLAS leaf range [%d,+%d) outside the index array", n.leftFirst, n.count);
+        enc = ~((n.leftFirst << 4) | n.count);
+        return RZ_OK;
+    };
+    int maxSlot = 0;
+    V.depth = 1;
+    if (root.count >= 0) {      // the root is a leaf (count 0: empty mesh, BVH.cpp:115-118)
+        V.empty = (root.count == 0);
+        int rc = leafEnc(root, V.rootEnc);
+        if (rc != RZ_OK) return rc;
+        maxSlot = root.leftFirst + root.count;
+    } else {
+        struct Item { int node; int depth; };
+        std::vector<Item> queue;
+        queue.push_back({0, 1});
+        V.rootEnc = 0;          // the root's pair is pair 0 of the view
+        size_t head = 0;
+        // pair index of an internal node = its rank among internal nodes in BFS order
+        while (head < queue.size()) {
+            Item it = queue[head++];
+            const rz_bvh_node& n = nodes[nodeOff + it.node];
+            const int L = n.leftFirst, R = n.leftFirst + 1;
+            if (L < 1 || (long long)nodeOff + R >= nNodes)
+                return fail(c, RZ_ERR_BAD_SCENE, "BLAS node %d has children %d,%d outside the node array", it.node, L, R);
+            if (queue.size() > (size_t)nNodes) return fail(c, RZ_ERR_BAD_SCENE, "BLAS at node offset %d is not a tree", nodeOff);
+            DevPair P{};
+            const rz_bvh_node& ln = nodes[nodeOff + L];
+            const rz_bvh_node& rn = nodes[nodeOff + R];
+            std::memcpy(P.lmin, ln.boundsMin, 12); std::memcpy(P.lmax, ln.boundsMax, 12);
+            std::memcpy(P.rmin, rn.boundsMin, 12); std::memcpy(P.rmax, rn.boundsMax, 12);
+            V.depth = std::max(V.depth, it.depth + 1);
+            const rz_bvh_node* ch[2] = {&ln, &rn};
+            int32_t* encs[2] = {&P.lenc, &P.renc};
+            const int chIdx[2] = {L, R};
+            for (int k = 0; k < 2; ++k) {
+                if (ch[k]->count >= 0) {
+                    int e; int rc = leafEnc(*ch[k], e);
+                    if (rc != RZ_OK) return rc;
+                    *encs[k] = e;
+                    maxSlot = std::max(maxSlot, ch[k]->leftFirst + ch[k]->count);
+                } else {
+                    *encs[k] = (int)queue.size();      // BFS rank of this internal child == its pair index
+                    queue.push_back({chIdx[k], it.depth + 1});
+                }
+            }
+            c->hPairs.push_back(P);
+        }
+        // queue[i] is the i-th internal node in BFS order and its pair was pushed i-th: enc == i holds by construction
+    }
+    // gather triangles into leaf order
+    for (int s = 0; s < maxSlot; ++s) {
+        const long long src = (long long)gTriOff + idx[triOff + s];
+        if (src < 0 || src >= nTris) return fail(c, RZ_ERR_BAD_SCENE, "BLAS index %d -> triangle %lld outside the triangle array (%lld)", s, src, nTris);
+        const rz_triangle& t = tris[src];
+        DevTri d{};
+        d.v0[0] = t.v0[0]; d.v0[1] = t.v0[1]; d.v0[2] = t.v0[2];
+        d.e1x = t.v1[0] - t.v0[0]; d.e1y = t.v1[1] - t.v0[1]; d.e1z = t.v1[2] - t.v0[2];   // FS:392
+        d.e2x = t.v2[0] - t.v0[0]; d.e2y = t.v2[1] - t.v0[1]; d.e2z = t.v2[2] - t.v0[2];   // FS:393
+        d.mat = t.materialIndex;
+        d.src = (int32_t)src;
+        c->hTris.push_back(d);
+    }
+    return RZ_OK;
+}
+
+int tlas_depth(const rz_bvh_node* n, size_t count) {
+    if (count == 0) return 0;
+    int best = 1;
+    std::vector<std::pair<int, int>> st;
+    st.push_back({0, 1});
+    size_t visited = 0;
+    while (!st.empty()) {
+        auto [i, d] = st.back();
+        st.pop_back();
+        if (++visited > count) return -1;
+        best = std::max(best, d);
+        if (n[i].count <= 0) {   // the shader treats count <= 0 as internal (FS:470)
+            if (n[i].count == 0) continue;     // empty root written by the host builder
+            int L = n[i].leftFirst;
+            if (L < 1 || (size_t)L + 1 >= count) return -1;
+            st.push_back({L, d + 1});
+            st.push_back({L + 1, d + 1});
+        }
+    }
+    return best;
+}
+
+int finalize(rz_ctx* c) {
+    if (!(c->geomDirty || c->instDirty || c->tlasDirty || c->matDirty || c->lightDirty)) return RZ_OK;
+    for (int b : {RZ_BIND_TRIANGLES, RZ_BIND_MATERIALS, RZ_BIND_LIGHTS, RZ_BIND_TLAS_NODES, RZ_BIND_TLAS_INDICES,
+                  RZ_BIND_BLAS_NODES, RZ_BIND_BLAS_INDICES, RZ_BIND_INSTANCES})
+        if (!c->present[b]) return fail(c, RZ_ERR_NOT_READY, "binding %d has not been uploaded", b);
+
+    if (c->geomDirty) { c->views.clear(); c->hPairs.clear(); c->hTris.clear(); c->instDirty = true; }
+    if (c->instDirty) {
+        const rz_bvh_instance* inst = hostArr<rz_bvh_instance>(c, RZ_BIND_INSTANCES);
+        const size_t nInst = hostCount<rz_bvh_instance>(c, RZ_BIND_INSTANCES);
+        std::vector<DevInstance> dev(nInst);
+        bool grew = false;
+        c->maxBlasDepth = 1;
+        for (size_t i = 0; i < nInst; ++i) {
+            auto key = std::make_tuple(inst[i].blasNodeOffset, inst[i].blasTriOffset, inst[i].globalTriOffset);
+            auto it = c->views.find(key);
+            if (it == c->views.end()) {
+                BlasView V;
+                int rc = build_view(c, inst[i].blasNodeOffset, inst[i].blasTriOffset, inst[i].globalTriOffset, V);
+                if (rc != RZ_OK) { c->views.clear(); c->hPairs.clear(); c->hTris.clear(); c->geomDirty = true; return rc; }
+                it = c->views.emplace(key, V).first;
+                grew = true;
+            }
+            const BlasView& V = it->second;
+            DevInstance& D = dev[i];
+            std::memset(&D, 0, sizeof D);
+            for (int col = 0; col < 4; ++col)
+                for (int row = 0; row < 3; ++row) {
+                    D.inv[col * 3 + row] = inst[i].inverseTransform[col * 4 + row];
+                    D.fwd[col * 3 + row] = inst[i].transform[col * 4 + row];
+                }
+            std::memcpy(D.rootMin, V.rootMin, 12);
+            std::memcpy(D.rootMax, V.rootMax, 12);
+            D.rootEnc = V.rootEnc;
+            D.pairBase = V.pairBase;
+            D.triBase = V.triBase;
+            D.flags = V.empty ? 1 : 0;
+        }
+        for (auto& kv : c->views) c->maxBlasDepth = std::max(c->maxBlasDepth, kv.second.depth);
+        if (grew || c->geomDirty) {
+            int rc = upload_vec(c, c->dPairs, c->hPairs.data(), c->hPairs.size() * sizeof(DevPair));
+            if (rc != RZ_OK) return rc;
+            rc = upload_vec(c, c->dTris, c->hTris.data(), c->hTris.size() * sizeof(DevTri));
+            if (rc != RZ_OK) return rc;
+        }
+        int rc = upload_vec(c, c->dInst, dev.data(), dev.size() * sizeof(DevInstance));
+        if (rc != RZ_OK) return rc;
+        // the staging vector dies at scope exit: the copy must have left it
+        RZ_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    if (c->tlasDirty || c->instDirty) {
+        const rz_bvh_node* tn = hostArr<rz_bvh_node>(c, RZ_BIND_TLAS_NODES);
+        const size_t nTn = hostCount<rz_bvh_node>(c, RZ_BIND_TLAS_NODES);
+        const int32_t* ti = hostArr<int32_t>(c, RZ_BIND_TLAS_INDICES);
+        const size_t nTi = hostCount<int32_t>(c, RZ_BIND_TLAS_INDICES);
+        const size_t nInst = hostCount<rz_bvh_instance>(c, RZ_BIND_INSTANCES);
+        int d = tlas_depth(tn, nTn);
+        if (d < 0) return fail(c, RZ_ERR_BAD_SCENE, "TLAS node array is not a tree");
+        for (size_t i = 0; i < nTn; ++i)
+            if (tn[i].count > 0) {
+                if (tn[i].leftFirst < 0 || (size_t)tn[i].leftFirst + (size_t)tn[i].count > nTi)
+                    return fail(c, RZ_ERR_BAD_SCENE, "TLAS leaf %zu range outside the TLAS index array", i);
+                for (int k = 0; k < tn[i].count; ++k) {
+                    int ii = ti[tn[i].leftFirst + k];
+                    if (ii < 0 || (size_t)ii >= nInst)
+                        return fail(c, RZ_ERR_BAD_SCENE, "TLAS index %d names instance %d of %zu", tn[i].leftFirst + k, ii, nInst);
+                }
+            }
+        c->tlasDepth = std::max(d, 1);
+        int rc = upload_vec(c, c->dTlasNodes, tn, nTn * sizeof(rz_bvh_node));
+        if (rc != RZ_OK) return rc;
+        rc = upload_vec(c, c->dTlasIdx, ti, nTi * sizeof(int32_t));
+        if (rc != RZ_OK) return rc;
+    }
+    if (c->matDirty) {
+        int rc = upload_vec(c, c->dMat, c->host[RZ_BIND_MATERIALS].data(), c->host[RZ_BIND_MATERIALS].size());
+        if (rc != RZ_OK) return rc;
+    }
+    if (c->lightDirty) {
+        int rc = upload_vec(c, c->dLight, c->host[RZ_BIND_LIGHTS].data(), c->host[RZ_BIND_LIGHTS].size());
+        if (rc != RZ_OK) return rc;
+    }
+    // material indices are data the kernels index with: check them once
+    if (c->geomDirty || c->matDirty) {
+        const int nMat = (int)hostCount<rz_material>(c, RZ_BIND_MATERIALS);
+        for (const DevTri& t : c->hTris)
+            if (t.mat < 0 || t.mat >= nMat)
+                return fail(c, RZ_ERR_BAD_SCENE, "triangle %d has materialIndex %d, %d materials uploaded", t.src, t.mat, nMat);
+    }
+    // uploads read the caller-visible host copies: let them land before rz_update may patch those
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    c->geomDirty = c->instDirty = c->tlasDirty = c->matDirty = c->lightDirty = false;
+    return RZ_OK;
+}
+
+int do_render(rz_ctx* c, bool counted, rz_counters* out) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    if (!c->haveFrame) return fail(c, RZ_ERR_NOT_READY, "rz_set_frame has not been called");
+    RZ_HIP(c, hipSetDevice(c->device));
+    int rc = finalize(c);
+    if (rc != RZ_OK) return rc;
+    const rz_frame_params& f = c->frame;
+    const size_t nPix = (size_t)f.width * f.height;
+    float4* accum = nullptr;
+    if (c->extAccum) {
+        if (c->extAccumBytes < nPix * 16) return fail(c, RZ_ERR_BUFFER_SIZE, "bound accumulation buffer holds %zu bytes, frame needs %zu", c->extAccumBytes, nPix * 16);
+        accum = static_cast<float4*>(c->extAccum);
+    } else {
+        accum = static_cast<float4*>(c->ownAccum.p);
+    }
+    KParams K{};
+    K.pairs = static_cast<const DevPair*>(c->dPairs.p);
+    K.tris = static_cast<const DevTri*>(c->dTris.p);
+    K.instances = static_cast<const DevInstance*>(c->dInst.p);
+    K.tlasNodes = static_cast<const TlasNode*>(c->dTlasNodes.p);
+    K.tlasIndices = static_cast<const int32_t*>(c->dTlasIdx.p);
+    K.materials = static_cast<const DevMaterial*>(c->dMat.p);
+    K.lights = static_cast<const DevLight*>(c->dLight.p);
+    K.accum = accum;
+    K.ior = static_cast<float*>(c->dIor.p);
+    K.nTlasNodes = (int)hostCount<rz_bvh_node>(c, RZ_BIND_TLAS_NODES);
+    K.nLights = std::max(0, std::min<int>(f.num_lights, (int)hostCount<rz_light>(c, RZ_BIND_LIGHTS)));
+    K.nMaterials = (int)hostCount<rz_material>(c, RZ_BIND_MATERIALS);
+    K.width = f.width; K.height = f.height;
+    K.tilesX = (f.width + RZ_TILE_W - 1) / RZ_TILE_W;
+    K.tilesY = (f.height + RZ_TILE_H - 1) / RZ_TILE_H;
+    const int nTiles = K.tilesX * K.tilesY;
+    K.tileRank = f.tile_rank; K.tileNRanks = f.tile_nranks;
+    K.nLocalTiles = (nTiles - f.tile_rank + f.tile_nranks - 1) / f.tile_nranks;
+    K.maxBounces = f.bounce_budget > 0 ? f.bounce_budget : 5;      // FS:673
+    K.spp = f.spp; K.sampleBase = f.sample_base;
+    K.blasStackCap = std::max(1, c->maxBlasDepth - 1);
+    K.tlasStackCap = std::min(64, std::max(2, c->tlasDepth + 1));  // FS:460: stack[64]
+    std::memcpy(K.invView, f.inv_view, 64);
+    std::memcpy(K.invProj, f.inv_proj, 64);
+    std::memcpy(K.camPos, f.cam_pos, 12);
+    const size_t perWave = (size_t)K.blasStackCap * 512 + (size_t)K.tlasStackCap * 256;
+    if (perWave * 4 > 160 * 1024)
+        return fail(c, RZ_ERR_BAD_SCENE, "BLAS depth %d needs %zu B of LDS stack per wave; the limit is %d", c->maxBlasDepth, perWave, 40 * 1024);
+    if (counted) {
+        rc = ensure(c, c->dCounters, sizeof(DevCounters));
+        if (rc != RZ_OK) return rc;
+        RZ_HIP(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(DevCounters), c->stream));
+        K.counters = static_cast<DevCounters*>(c->dCounters.p);
+    }
+    RZ_HIP(c, hipEventRecord(c->evStart, c->stream));
+    launch_render_pixels(K, counted, c->stream);
+    RZ_HIP(c, hipGetLastError());
+    RZ_HIP(c, hipEventRecord(c->evStop, c->stream));
+    c->timed = true;
+    c->lastLaunches = 1;
+    if (counted && out) {
+        DevCounters h{};
+        RZ_HIP(c, hipMemcpyAsync(&h, c->dCounters.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        RZ_HIP(c, hipStreamSynchronize(c->stream));
+        out->samples = h.samples; out->traversals = h.traversals; out->tlas_nodes = h.tlas_nodes;
+        out->tlas_leaf_indices = h.tlas_leaf_indices; out->instances = h.instances; out->blas_nodes = h.blas_nodes;
+        out->triangles = h.triangles; out->materials = h.materials; out->light_fetches = h.light_fetches;
+        out->pixels = h.pixels;
+    }
+    return RZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rz_version(void) { return "rayzen_hip 0.1 (gfx950)"; }
+
+size_t rz_sizeof(int which) {
+    switch (which) {
+        case 0: return sizeof(rz_triangle);
+        case 1: return sizeof(rz_bvh_node);
+        case 2: return sizeof(rz_bvh_instance);
+        case 3: return sizeof(rz_material);
+        case 4: return sizeof(rz_light);
+        case 5: return sizeof(rz_frame_params);
+        case 6: return sizeof(rz_counters);
+        default: return 0;
+    }
+}
+
+const char* rz_last_error(const rz_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+rz_ctx* rz_create(int device, unsigned flags) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { fail(nullptr, RZ_ERR_NO_DEVICE, "no HIP device (%s)", hipGetErrorString(e)); return nullptr; }
+    if (device < 0 || device >= n) { fail(nullptr, RZ_ERR_INVALID_ARG, "device %d of %d", device, n); return nullptr; }
+    rz_ctx* c = new (std::nothrow) rz_ctx();
+    if (!c) { fail(nullptr, RZ_ERR_HIP, "out of host memory"); return nullptr; }
+    c->device = device;
+    c->flags = flags;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->evStart) != hipSuccess || hipEventCreate(&c->evStop) != hipSuccess) {
+        fail(nullptr, RZ_ERR_HIP, "cannot create stream/events on device %d", device);
+        delete c;
+        return nullptr;
+    }
+    c->stream = c->ownStream;
+    return c;
+}
+
+void rz_destroy(rz_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
+                      &c->dCounters, &c->dResolve, &c->ownAccum, &c->dIor})
+        b->release();
+    if (c->evStart) (void)hipEventDestroy(c->evStart);
+    if (c->evStop) (void)hipEventDestroy(c->evStop);
+    if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
+    delete c;
+}
+
+int rz_upload(rz_ctx* c, rz_binding binding, const void* data, size_t bytes) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    const size_t es = elem_size((int)binding);
+    if (es == 0) return fail(c, RZ_ERR_INVALID_ARG, "unknown binding %d", (int)binding);
+    if (bytes % es) return fail(c, RZ_ERR_INVALID_ARG, "binding %d: %zu bytes is not a multiple of the %zu-byte element", (int)binding, bytes, es);
+    if (bytes && !data) return fail(c, RZ_ERR_INVALID_ARG, "null data");
+    try {
+        c->host[binding].assign(static_cast<const unsigned char*>(data), static_cast<const unsigned char*>(data) + bytes);
+    } catch (...) { return fail(c, RZ_ERR_HIP, "out of host memory"); }
+    c->present[binding] = true;
+    switch (binding) {
+        case RZ_BIND_MATERIALS: c->matDirty = true; break;
+        case RZ_BIND_LIGHTS: c->lightDirty = true; break;
+        case RZ_BIND_TLAS_NODES: case RZ_BIND_TLAS_INDICES: c->tlasDirty = true; break;
+        case RZ_BIND_INSTANCES: c->instDirty = true; break;
+        default: c->geomDirty = true; break;
+    }
+    return RZ_OK;
+}
+
+int rz_update(rz_ctx* c, rz_binding binding, size_t offset, const void* data, size_t bytes) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    if (elem_size((int)binding) == 0) return fail(c, RZ_ERR_INVALID_ARG, "unknown binding %d", (int)binding);
+    if (!c->present[binding]) return fail(c, RZ_ERR_NOT_READY, "binding %d has not been uploaded", (int)binding);
+    if (bytes && !data) return fail(c, RZ_ERR_INVALID_ARG, "null data");
+    if (offset > c->host[binding].size() || bytes > c->host[binding].size() - offset)
+        return fail(c, RZ_ERR_OUT_OF_RANGE, "binding %d: update [%zu,+%zu) past its %zu bytes", (int)binding, offset, bytes, c->host[binding].size());
+    if (bytes == 0) return RZ_OK;
+    if (std::memcmp(c->host[binding].data() + offset, data, bytes) == 0) return RZ_OK;   // unchanged: nothing to redo
+    std::memcpy(c->host[binding].data() + offset, data, bytes);
+    switch (binding) {
+        case RZ_BIND_MATERIALS: c->matDirty = true; break;
+        case RZ_BIND_LIGHTS: c->lightDirty = true; break;
+        case RZ_BIND_TLAS_NODES: case RZ_BIND_TLAS_INDICES: c->tlasDirty = true; break;
+        case RZ_BIND_INSTANCES: c->instDirty = true; break;
+        default: c->geomDirty = true; break;
+    }
+    return RZ_OK;
+}
+
+int rz_set_frame(rz_ctx* c, const rz_frame_params* p) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    if (!p) return fail(c, RZ_ERR_INVALID_ARG, "null params");
+    if (p->width <= 0 || p->height <= 0 || (long long)p->width * p->height > (1ll << 28))
+        return fail(c, RZ_ERR_INVALID_ARG, "resolution %dx%d", p->width, p->height);
+    if (p->spp <= 0) return fail(c, RZ_ERR_INVALID_ARG, "spp %d", p->spp);
+    if (p->sample_base < 0) return fail(c, RZ_ERR_INVALID_ARG, "sample_base %d", p->sample_base);
+    if (p->tile_nranks < 1 || p->tile_rank < 0 || p->tile_rank >= p->tile_nranks)
+        return fail(c, RZ_ERR_INVALID_ARG, "tile_rank %d of %d", p->tile_rank, p->tile_nranks);
+    RZ_HIP(c, hipSetDevice(c->device));
+    const size_t nPix = (size_t)p->width * p->height;
+    const bool resized = !c->haveFrame || c->frame.width != p->width || c->frame.height != p->height;
+    if (resized) {
+        int rc = ensure(c, c->dIor, nPix * sizeof(float));
+        if (rc != RZ_OK) return rc;
+        if (!c->extAccum) {
+            rc = ensure(c, c->ownAccum, nPix * 16);
+            if (rc != RZ_OK) return rc;
+            RZ_HIP(c, hipMemsetAsync(c->ownAccum.p, 0, nPix * 16, c->stream));
+        }
+    }
+    c->frame = *p;
+    c->haveFrame = true;
+    return RZ_OK;
+}
+
+int rz_set_stream(rz_ctx* c, void* hip_stream) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    (void)hipStreamSynchronize(c->stream);
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->ownStream;
+    return RZ_OK;
+}
+
+int rz_bind_accum(rz_ctx* c, void* device_rgba, size_t bytes) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    c->extAccum = device_rgba;
+    c->extAccumBytes = device_rgba ? bytes : 0;
+    if (!device_rgba && c->haveFrame) {
+        const size_t nPix = (size_t)c->frame.width * c->frame.height;
+        RZ_HIP(c, hipSetDevice(c->device));
+        int rc = ensure(c, c->ownAccum, nPix * 16);
+        if (rc != RZ_OK) return rc;
+        RZ_HIP(c, hipMemsetAsync(c->ownAccum.p, 0, nPix * 16, c->stream));
+    }
+    return RZ_OK;
+}
+
+int rz_render(rz_ctx* c) { return do_render(c, false, nullptr); }
+int rz_render_counted(rz_ctx* c, rz_counters* out) { return do_render(c, true, out); }
+
+int rz_sync(rz_ctx* c) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    return RZ_OK;
+}
+
+void* rz_accum_device_ptr(rz_ctx* c) {
+    if (!c) return nullptr;
+    return c->extAccum ? c->extAccum : c->ownAccum.p;
+}
+
+int rz_clear_accum(rz_ctx* c) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    if (!c->haveFrame) return fail(c, RZ_ERR_NOT_READY, "rz_set_frame has not been called");
+    void* p = rz_accum_device_ptr(c);
+    RZ_HIP(c, hipMemsetAsync(p, 0, (size_t)c->frame.width * c->frame.height * 16, c->stream));
+    return RZ_OK;
+}
+
+int rz_read_accum(rz_ctx* c, float* rgba, size_t bytes) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    if (!c->haveFrame) return fail(c, RZ_ERR_NOT_READY, "rz_set_frame has not been called");
+    const size_t need = (size_t)c->frame.width * c->frame.height * 16;
+    if (!rgba || bytes < need) return fail(c, RZ_ERR_BUFFER_SIZE, "rz_read_accum needs %zu bytes, got %zu", need, bytes);
+    RZ_HIP(c, hipMemcpyAsync(rgba, rz_accum_device_ptr(c), need, hipMemcpyDeviceToHost, c->stream));
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    return RZ_OK;
+}
+
+int rz_resolve_rgba8(rz_ctx* c, uint8_t* rgba8, size_t bytes) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    if (!c->haveFrame) return fail(c, RZ_ERR_NOT_READY, "rz_set_frame has not been called");
+    const size_t nPix = (size_t)c->frame.width * c->frame.height;
+    if (!rgba8 || bytes < nPix * 4) return fail(c, RZ_ERR_BUFFER_SIZE, "rz_resolve_rgba8 needs %zu bytes, got %zu", nPix * 4, bytes);
+    int rc = ensure(c, c->dResolve, nPix * 4);
+    if (rc != RZ_OK) return rc;
+    launch_resolve(static_cast<const float4*>(rz_accum_device_ptr(c)), static_cast<uchar4*>(c->dResolve.p), (int)nPix, c->stream);
+    RZ_HIP(c, hipGetLastError());
+    RZ_HIP(c, hipMemcpyAsync(rgba8, c->dResolve.p, nPix * 4, hipMemcpyDeviceToHost, c->stream));
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    return RZ_OK;
+}
+
+int rz_last_render_ms(rz_ctx* c, float* ms, int* launches) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    if (!c->timed) return fail(c, RZ_ERR_NOT_READY, "nothing rendered yet");
+    RZ_HIP(c, hipEventSynchronize(c->evStop));
+    float t = 0.0f;
+    RZ_HIP(c, hipEventElapsedTime(&t, c->evStart, c->evStop));
+    if (ms) *ms = t;
+    if (launches) *launches = c->lastLaunches;
+    return RZ_OK;
+}
+
+}  // extern "C"

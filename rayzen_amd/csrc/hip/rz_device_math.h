@@ -1,0 +1,146 @@
+// rz_device_math.h -- arithmetic of the path tracer on gfx950.
+//
+// The renderer must reproduce RayZen's fragment shader (RayZen/shaders/
+// fragment_shader.glsl, "FS") decision for decision: its random numbers are
+// fract(sin(x)*43758.5453) of arguments up to ~1e10, so one ulp anywhere
+// upstream flips whole paths.  Hence:
+//   * every float operation below is a single IEEE binary32 operation in the
+//     shader's operand order; the translation unit is compiled with
+//     -ffp-contract=off so hipcc emits v_mul_f32 + v_add_f32, never v_fmac;
+//     division and sqrt are the correctly rounded forms (hipcc default
+//     -fhip-fp32-correctly-rounded-divide-sqrt);
+//   * GLSL min/max/clamp = v_min_f32 / v_max_f32 (IEEE minNum/maxNum: the
+//     non-NaN operand wins), which is also what a GPU running FS does;
+//   * sin/cos/acos, which GLSL leaves to the driver, are defined here once
+//     and for all: binary64 evaluation built only from fma, mul, add, div,
+//     sqrt, rint and floor (each exactly specified by IEEE-754), rounded once
+//     to binary32.  Cody-Waite reduction by pi/2 in three fma steps, then the
+//     classic fdlibm minimax polynomials (k_sin.c / k_cos.c / e_acos.c
+//     coefficients).  v_fma_f64 runs at half the f32 rate on CDNA4 and these
+//     are a few dozen operations per bounce: noise next to BVH traversal.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rz {
+
+struct v3 { float x, y, z; };
+struct v2 { float x, y; };
+
+__device__ __forceinline__ v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, v3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ v3 operator/(v3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ v3 operator-(v3 a) { return mk3(-a.x, -a.y, -a.z); }
+// GLSL dot / cross, evaluated left to right
+__device__ __forceinline__ float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ v3 cross(v3 a, v3 b) {
+    return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+__device__ __forceinline__ float length(v3 a) { return __builtin_sqrtf(dot(a, a)); }
+__device__ __forceinline__ v3 normalize(v3 a) { return a / __builtin_sqrtf(dot(a, a)); }
+
+__device__ __forceinline__ float fmin_(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float clamp_(float x, float lo, float hi) { return fmin_(fmax_(x, lo), hi); }
+__device__ __forceinline__ float mix_(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+__device__ __forceinline__ float fract_(float x) { return x - __builtin_floorf(x); }
+__device__ __forceinline__ float pow2_(float x) { return x * x; }
+__device__ __forceinline__ float pow5_(float x) { float x2 = x * x; float x4 = x2 * x2; return x4 * x; }
+
+// column-major mat4 (16 floats) applied to (v,1) / (v,0); rows 0..2 only
+__device__ __forceinline__ v3 xform_point(const float* m, v3 v) {
+    return mk3(((m[0] * v.x + m[4] * v.y) + m[8] * v.z) + m[12],
+               ((m[1] * v.x + m[5] * v.y) + m[9] * v.z) + m[13],
+               ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[14]);
+}
+__device__ __forceinline__ v3 xform_dir(const float* m, v3 v) {
+    return mk3((m[0] * v.x + m[4] * v.y) + m[8] * v.z,
+               (m[1] * v.x + m[5] * v.y) + m[9] * v.z,
+               (m[2] * v.x + m[6] * v.y) + m[10] * v.z);
+}
+// mat3(transpose(m)) * v
+__device__ __forceinline__ v3 xform_normal(const float* m, v3 v) {
+    return mk3((m[0] * v.x + m[1] * v.y) + m[2] * v.z,
+               (m[4] * v.x + m[5] * v.y) + m[6] * v.z,
+               (m[8] * v.x + m[9] * v.y) + m[10] * v.z);
+}
+
+// ---- sin / cos / acos -----------------------------------------------------
+struct SinCos { double s, c; int q; };
+
+__device__ __forceinline__ SinCos sincos_core(float xf) {
+    const double x = (double)xf;
+    const double k = __builtin_rint(x * 6.36619772367581382433e-01);
+    double r = __builtin_fma(-k, 1.57079632673412561417e+00, x);
+    r = __builtin_fma(-k, 6.07710050630396597660e-11, r);
+    r = __builtin_fma(-k, 2.02226624871116645580e-21, r);
+    const double q = k - 4.0 * __builtin_floor(k * 0.25);
+    const double z = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    SinCos o;
+    o.s = __builtin_fma(z * r, ps, r);
+    o.c = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+    o.q = (int)q;
+    return o;
+}
+__device__ __forceinline__ float sin_(float x) {
+    SinCos t = sincos_core(x);
+    double v = (t.q & 1) ? t.c : t.s;
+    if (t.q & 2) v = -v;
+    return (float)v;
+}
+__device__ __forceinline__ float cos_(float x) {
+    SinCos t = sincos_core(x);
+    double v = (t.q & 1) ? t.s : t.c;
+    if ((t.q + 1) & 2) v = -v;
+    return (float)v;
+}
+__device__ __forceinline__ float acos_(float xf) {
+    const double x = (double)xf;
+    const double ax = __builtin_fabs(x);
+    if (!(ax < 1.0)) {
+        if (x != x) return xf;
+        return (x > 0.0) ? 0.0f : (float)3.14159265358979311600e+00;
+    }
+    const bool small = ax < 0.5;
+    const double z = small ? x * x : (1.0 - ax) * 0.5;
+    double p = __builtin_fma(z, 3.47933107596021167570e-05, 7.91534994289814532176e-04);
+    p = __builtin_fma(z, p, -4.00555345006794114027e-02);
+    p = __builtin_fma(z, p, 2.01212532134862925881e-01);
+    p = __builtin_fma(z, p, -3.25565818622400915405e-01);
+    p = __builtin_fma(z, p, 1.66666666666666657415e-01);
+    p = p * z;
+    double q = __builtin_fma(z, 7.70381505559019352791e-02, -6.88283971605453293030e-01);
+    q = __builtin_fma(z, q, 2.02094576023350569471e+00);
+    q = __builtin_fma(z, q, -2.40339491173441421878e+00);
+    q = __builtin_fma(z, q, 1.0);
+    const double R = p / q;
+    double res;
+    if (small) {
+        res = 1.57079632679489655800e+00 - __builtin_fma(x, R, x);
+    } else {
+        const double s = __builtin_sqrt(z);
+        const double t = 2.0 * __builtin_fma(s, R, s);
+        res = (x > 0.0) ? t : 3.14159265358979311600e+00 - t;
+    }
+    return (float)res;
+}
+
+// FS:188-190
+__device__ __forceinline__ float rand_(v2 uv) {
+    float d = uv.x * 12.9898f + uv.y * 78.233f;
+    return fract_(sin_(d) * 43758.5453f);
+}
+
+}  // namespace rz

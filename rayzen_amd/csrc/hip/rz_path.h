@@ -1,0 +1,295 @@
+// rz_path.h -- the per-pixel path loop of FS:668-773 as a state machine.
+//
+// The shader nests everything: bounce loop -> calculateLighting -> light loop
+// -> shadowVisibility -> up to 32 closest-hit traversals.  Compiled as
+// written that is five traversal call sites, each inlined.  Here a path is
+// a small record that is advanced from one closest-hit query to the next:
+//
+//     ray ready --trace--> advance(hit) --> next ray ready | sample finished
+//
+// with two kinds of ray in flight: a path segment (primary / bounce) or one
+// iteration of a shadow query.  There is a single trace call site, lanes of
+// a wave can be in different phases while sharing the traversal loop, and the
+// same record can be parked in memory by a queued ("wavefront") pipeline.
+// The arithmetic, statement by statement, is the shader's.
+#pragma once
+#include "rz_trace.h"
+
+namespace rz {
+
+enum : int { MODE_SEGMENT = 0, MODE_SHADOW = 1, MODE_DONE = 2 };
+
+struct Path {
+    // per pixel
+    v2 uv;              // gl_FragCoord.xy / resolution (FS:669)
+    float fragSum;      // gl_FragCoord.x + gl_FragCoord.y
+    v3 color;           // running sum over samples (FS:672; divide/clamp of FS:772-773 are the resolve's job)
+    float ior;          // currentIor: declared OUTSIDE the sample loop (FS:674), so it carries over
+    // per sample
+    int samp, sampEnd;
+    v2 seed;            // FS:688
+    int bounce;
+    v3 throughput;
+    // the ray to trace next
+    v3 o, d;
+    int mode;
+    // bounce-0 direct lighting in progress (FS:569-663), parked while shadow rays fly
+    v3 hp, hn, pdir;    // the surface point being lit, its normal, the direction the path arrived with
+    int hmat;
+    v3 lacc;            // finalColor / specAccum
+    int li;             // light index
+    float vis, traveled, maxDist;
+    int iter;
+};
+
+// FS:204-212 + FS:688-692
+template <bool COUNT>
+__device__ __forceinline__ void begin_sample(const KParams& K, Path& P, Tally& c) {
+    if (COUNT) c.samples += 1;
+    const float sf = ((P.fragSum + (float)P.samp) + 1.0f);
+    P.seed.x = P.uv.x * sf;
+    P.seed.y = P.uv.y * sf;
+    v2 s1; s1.x = P.seed.x + 1.0f; s1.y = P.seed.y + 1.0f;
+    const float jx = rand_(P.seed) * 0.00002f, jy = rand_(s1) * 0.00002f;
+    const float ux = P.uv.x + jx, uy = P.uv.y + jy;
+    const float cx = ux * 2.0f - 1.0f, cy = uy * 2.0f - 1.0f;
+    const float* ip = K.invProj;
+    const float ex = ((ip[0] * cx + ip[4] * cy) + ip[8] * -1.0f) + ip[12] * 1.0f;
+    const float ey = ((ip[1] * cx + ip[5] * cy) + ip[9] * -1.0f) + ip[13] * 1.0f;
+    const v3 world = xform_dir(K.invView, mk3(ex, ey, -1.0f));
+    P.o = mk3(K.camPos[0], K.camPos[1], K.camPos[2]);
+    P.d = normalize(world);
+    P.throughput = mk3(1.0f, 1.0f, 1.0f);
+    P.bounce = 0;
+    P.mode = MODE_SEGMENT;
+}
+
+__device__ __forceinline__ void end_sample(Path& P) {
+    P.samp += 1;
+    P.mode = MODE_DONE;     // caller restarts with begin_sample if samp < sampEnd
+}
+
+// FS:533-535
+__device__ __forceinline__ v3 fresnel_schlick(float cosTheta, v3 F0) {
+    const float p = pow5_(1.0f - cosTheta);
+    return mk3(F0.x + (1.0f - F0.x) * p, F0.y + (1.0f - F0.y) * p, F0.z + (1.0f - F0.z) * p);
+}
+// FS:537-539
+__device__ __forceinline__ v3 reflect_ray(v3 i, v3 n) { return i - n * (2.0f * dot(i, n)); }
+// FS:558-567
+__device__ __forceinline__ bool refract_dir(v3 incident, v3 normal, float eta, v3& refr) {
+    const float cosi = clamp_(dot(-incident, normal), -1.0f, 1.0f);
+    const float sint2 = fmax_(0.0f, 1.0f - cosi * cosi);
+    const float k = 1.0f - (eta * eta) * sint2;
+    if (k < 0.0f) return false;
+    const float w = eta * cosi - __builtin_sqrtf(k);
+    refr = normalize(incident * eta + normal * w);
+    return true;
+}
+// FS:192-202
+__device__ __forceinline__ v3 random_hemisphere_direction(v3 normal, v2 seed) {
+    const float u = rand_(seed);
+    v2 s1; s1.x = seed.x + 1.0f; s1.y = seed.y + 1.0f;
+    const float v = rand_(s1);
+    const float theta = acos_(__builtin_sqrtf(1.0f - u));
+    const float phi = (2.0f * 3.14159f) * v;
+    const float st = sin_(theta), ct = cos_(theta), sp = sin_(phi), cp = cos_(phi);
+    const v3 dir = mk3(st * cp, st * sp, ct);
+    const v3 up = (__builtin_fabsf(normal.y) < 0.99f) ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
+    const v3 tangent = normalize(cross(up, normal));
+    const v3 bitangent = cross(normal, tangent);
+    return normalize((tangent * dir.x + bitangent * dir.y) + normal * dir.z);
+}
+
+// Set up the shadow query of light P.li for the parked surface point
+// (FS:578-588 transparent branch, FS:622-635 opaque branch).
+template <bool COUNT>
+__device__ __forceinline__ void start_light(const KParams& K, Path& P, Tally& c) {
+    const DevLight L = K.lights[P.li];
+    const DevMaterial M = K.materials[P.hmat];
+    if (COUNT) c.light_fetches += 1;
+    v3 dir;
+    if (L.posdir[3] == 1.0f) {
+        const v3 lv = mk3(L.posdir[0], L.posdir[1], L.posdir[2]) - P.hp;
+        const float dist = fmax_(length(lv), 0.001f);
+        dir = (M.transparency > 0.0f) ? lv / dist : normalize(lv);
+        P.maxDist = dist;
+    } else {
+        dir = normalize(mk3(L.posdir[0], L.posdir[1], L.posdir[2]));
+        P.maxDist = 1e30f;
+    }
+    P.o = P.hp + dir * 0.001f;
+    P.d = dir;
+    P.vis = 1.0f;
+    P.traveled = 0.0f;
+    P.iter = 0;
+    P.mode = MODE_SHADOW;
+}
+
+// The light P.li is visible with P.vis: add its term (FS:589-607 / FS:636-659).
+__device__ __forceinline__ void shade_light(const KParams& K, Path& P) {
+    const DevLight L = K.lights[P.li];
+    const DevMaterial M = K.materials[P.hmat];
+    const v3 lightDir = P.d;
+    const v3 normal = P.hn;
+    const v3 viewDir = normalize(mk3(K.camPos[0], K.camPos[1], K.camPos[2]) - P.hp);   // FS:714
+    const v3 albedo = mk3(M.albedo[0], M.albedo[1], M.albedo[2]);
+    const v3 lcolor = mk3(L.color[0], L.color[1], L.color[2]);
+    float attenuation = (L.posdir[3] == 1.0f) ? L.power / (P.maxDist * P.maxDist) : L.power;
+    attenuation *= P.vis;
+    if (M.transparency > 0.0f) {
+        const float NdotL = fmax_(dot(normal, lightDir), 0.0f);
+        if (NdotL <= 0.0f) return;
+        const float f0 = pow2_((1.0f - M.ior) / (1.0f + M.ior));
+        const v3 H = normalize(lightDir + viewDir);
+        const float NdotH = fmax_(dot(normal, H), 0.0f);
+        const float cosTheta = fmax_(dot(H, viewDir), 0.0f);
+        const v3 F = fresnel_schlick(cosTheta, mk3(f0, f0, f0));
+        const float rough = fmax_(M.roughness, 0.02f);
+        const float a = rough * rough;
+        const float a2 = a * a;
+        const float dDen = (NdotH * NdotH) * (a2 - 1.0f) + 1.0f;
+        const float D = a2 / ((3.14159f * dDen) * dDen + 1e-6f);
+        const float k = (rough + 1.0f) * (rough + 1.0f) / 8.0f;
+        const float NdotV = fmax_(dot(normal, viewDir), 0.0f);
+        const float Gv = NdotV / ((NdotV * (1.0f - k) + k) + 1e-6f);
+        const float Gl = NdotL / ((NdotL * (1.0f - k) + k) + 1e-6f);
+        const float denom = fmax_((4.0f * NdotL) * NdotV, 1e-4f);
+        const v3 spec = (((F * D) * Gv) * Gl) / denom;
+        P.lacc = P.lacc + ((spec * lcolor) * attenuation) * NdotL;
+    } else {
+        const v3 F0 = mk3(mix_(0.04f, albedo.x, M.metallic), mix_(0.04f, albedo.y, M.metallic),
+                          mix_(0.04f, albedo.z, M.metallic));
+        const v3 halfwayDir = normalize(lightDir + viewDir);
+        const float NdotL = fmax_(dot(normal, lightDir), 0.0f);
+        const float NdotV = fmax_(dot(normal, viewDir), 0.0f);
+        const v3 F = fresnel_schlick(fmax_(dot(halfwayDir, viewDir), 0.0f), F0);
+        const float alpha = M.roughness * M.roughness;
+        const float alpha2 = alpha * alpha;
+        const float ndh = dot(normal, halfwayDir);
+        const float denom = (ndh * ndh) * (alpha2 - 1.0f) + 1.0f;
+        const float D = alpha2 / ((3.14159f * denom) * denom);
+        const float k = (M.roughness + 1.0f) * (M.roughness + 1.0f) / 8.0f;
+        float G = NdotV / (NdotV * (1.0f - k) + k);
+        G *= NdotL / (NdotL * (1.0f - k) + k);
+        const float denomSpec = fmax_((4.0f * NdotV) * NdotL, 0.0001f);
+        const v3 specular = ((F * D) * G) / denomSpec;
+        const v3 oneMinusF = mk3(1.0f - F.x, 1.0f - F.y, 1.0f - F.z);
+        const v3 diffuse = ((oneMinusF * albedo) * NdotL) / 3.14159f;
+        const v3 t = ((diffuse + specular) * lcolor) * attenuation;
+        P.lacc = P.lacc + mk3(fmax_(0.0f, t.x), fmax_(0.0f, t.y), fmax_(0.0f, t.z));
+    }
+}
+
+// FS:720-769: choose the next direction at the parked surface point and move on.
+__device__ __forceinline__ void scatter(const KParams& K, Path& P) {
+    const DevMaterial M = K.materials[P.hmat];
+    const float fb2 = (float)(P.bounce * P.bounce), fb = (float)P.bounce;
+    v2 tempseed;
+    tempseed.x = (P.seed.x * fb2) * 12793.46f + fb * 1423.34f;
+    tempseed.y = (P.seed.y * fb2) * 12793.46f + fb * 1423.34f;
+    v2 rs; rs.x = tempseed.x + (float)P.samp; rs.y = tempseed.y + fb;
+    const float randVal = rand_(rs);
+    const v3 hitNormal = P.hn;
+    v3 dir = P.pdir;
+    if (M.transparency > 0.0f) {
+        const bool entering = dot(-dir, hitNormal) > 0.0f;
+        const v3 N = entering ? hitNormal : -hitNormal;
+        const float extIor = P.ior;
+        const float nextIor = entering ? M.ior : 1.0f;
+        const float eta = extIor / nextIor;
+        const float cosi = clamp_(dot(-dir, N), 0.0f, 1.0f);
+        const float F0 = pow2_((extIor - nextIor) / (extIor + nextIor));
+        const float fresnel = F0 + (1.0f - F0) * pow5_(1.0f - cosi);
+        v3 refr;
+        if (!refract_dir(dir, N, eta, refr)) {
+            dir = reflect_ray(dir, N);
+            P.throughput = P.throughput * 0.98f;
+        } else {
+            dir = refr;
+            P.ior = nextIor;
+            const float tr = M.transparency;
+            const v3 tint = mk3(mix_(1.0f, M.albedo[0], tr), mix_(1.0f, M.albedo[1], tr), mix_(1.0f, M.albedo[2], tr));
+            const v3 tw = (tint * tr) * (1.0f - fresnel);
+            P.throughput = P.throughput * mk3(clamp_(tw.x, 0.0f, 1.0f), clamp_(tw.y, 0.0f, 1.0f), clamp_(tw.z, 0.0f, 1.0f));
+        }
+    } else {
+        if (randVal < M.reflectivity) {
+            dir = reflect_ray(dir, hitNormal);
+            P.throughput = P.throughput * 0.95f;
+        } else {
+            dir = random_hemisphere_direction(hitNormal, tempseed);
+            P.throughput = P.throughput * (mk3(M.albedo[0], M.albedo[1], M.albedo[2]) * 0.4f);
+        }
+    }
+    const float pushDir = dot(dir, hitNormal) > 0.0f ? 1.0f : -1.0f;
+    P.o = P.hp + (hitNormal * pushDir) * 0.003f;
+    P.d = dir;
+    P.mode = MODE_SEGMENT;
+    if (P.bounce > 2) {     // Russian roulette with the SAME random number (FS:764-769)
+        const float p = fmax_(P.throughput.x, fmax_(P.throughput.y, P.throughput.z));
+        if (randVal > p) { end_sample(P); return; }
+        P.throughput = P.throughput / p;
+    }
+    P.bounce += 1;
+    if (P.bounce >= K.maxBounces) end_sample(P);
+}
+
+// Lighting of the parked point is complete (or there are no lights): FS:717, then scatter.
+__device__ __forceinline__ void finish_lighting(const KParams& K, Path& P) {
+    P.color = P.color + P.throughput * P.lacc;
+    scatter(K, P);
+}
+
+// Advance a path by the result of the closest-hit query of its current ray.
+template <bool COUNT>
+__device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, const HitRec& h, Tally& c) {
+    if (P.mode == MODE_SEGMENT) {
+        if (!found) {   // FS:705-711
+            const float t = 0.5f * (normalize(P.d).y + 1.0f);
+            const v3 sky = mk3(mix_(0.15f, 0.5f, t), mix_(0.25f, 0.7f, t), mix_(0.45f, 1.0f, t));
+            P.color = P.color + P.throughput * sky;
+            end_sample(P);
+            return;
+        }
+        if (COUNT) c.materials += 1;        // FS:713
+        P.hp = h.p; P.hn = h.n; P.hmat = h.mat; P.pdir = P.d;
+        if (P.bounce == 0) {                // FS:716-718
+            const DevMaterial M = K.materials[h.mat];
+            P.lacc = (M.transparency > 0.0f)
+                         ? mk3(0.0f, 0.0f, 0.0f)
+                         : mk3(0.05f * M.albedo[0], 0.05f * M.albedo[1], 0.05f * M.albedo[2]);
+            P.li = 0;
+            if (K.nLights > 0) { start_light<COUNT>(K, P, c); return; }
+            finish_lighting(K, P);
+            return;
+        }
+        scatter(K, P);
+        return;
+    }
+    // MODE_SHADOW: the body of one iteration of FS:511-526
+    bool done = false, lit = false;
+    if (!found) { done = true; lit = true; }
+    else if (h.t < 0.001f) { P.o = P.o + P.d * 0.001f; }
+    else {
+        P.traveled += h.t;
+        if (P.traveled >= P.maxDist) { done = true; lit = true; }
+        else {
+            if (COUNT) c.materials += 1;
+            const float tr = K.materials[h.mat].transparency;
+            if (tr > 0.0f) { P.vis *= tr; P.o = h.p + P.d * 0.001f; }
+            else { P.vis = 0.0f; done = true; lit = false; }
+        }
+    }
+    if (!done) {
+        P.iter += 1;
+        if (P.iter < 32 && P.vis > 0.05f) return;   // next iteration: trace again
+        lit = P.vis > 0.05f;                         // FS:527
+    }
+    if (lit) shade_light(K, P);
+    P.li += 1;
+    if (P.li < K.nLights) { start_light<COUNT>(K, P, c); return; }
+    finish_lighting(K, P);
+}
+
+}  // namespace rz

@@ -1,0 +1,102 @@
+// rz_scene_dev.h -- how the scene lives in HBM.
+//
+// The C-ABI receives RayZen's SSBO arrays verbatim (include/rayzen_hip.h).
+// They are re-laid-out ONCE, when a frame is rendered after an upload
+// (rz_context.hip: finalize), into the structures below.  Nothing about the
+// re-layout changes a single float the traversal computes: boxes and
+// vertices are copied bit for bit, edge vectors are the same one-rounding
+// subtractions FS:392-393 perform per test, and child / triangle visiting
+// order is the reference's.
+//
+//  * DevPair (64 B, 64-B aligned): the two children of one internal BLAS
+//    node -- their boxes and an encoded reference each.  RayZen allocates
+//    children as adjacent pairs (BVH.cpp:166-171) and its shader fetches them
+//    separately when popped; here one aligned 64-B record (4 x dwordx4 per
+//    lane, one cache line) serves both box tests at the moment the parent is
+//    expanded.
+//  * enc: >= 0  -> internal child: index of ITS DevPair (relative to the
+//                  BLAS's pair base);
+//         <  0  -> leaf child: ~enc = (firstSlot << 4) | count, count 0..15,
+//                  firstSlot relative to the BLAS's triangle base.
+//  * DevTri (48 B = 3 x dwordx4): triangles gathered into LEAF ORDER, which
+//    removes the blasTriIndices indirection (FS:434) and makes a leaf's <=4
+//    triangles contiguous.  v0, e1 = v1 - v0, e2 = v2 - v0, materialIndex.
+//  * DevInstance (144 B): the 3x4 parts of transform / inverseTransform the
+//    shader actually uses (FS:476-477,484,489), the BLAS root box + enc (so
+//    the root test needs no node fetch) and the bases of its pair / triangle
+//    ranges.
+//  * TLAS nodes and indices keep RayZen's 32-B node layout: a TLAS has a
+//    handful of nodes and is traversed literally (FS:457-503).
+#pragma once
+#include <stdint.h>
+
+namespace rz {
+
+struct alignas(64) DevPair {
+    float lmin[3]; int32_t lenc;
+    float lmax[3]; int32_t lpad;
+    float rmin[3]; int32_t renc;
+    float rmax[3]; int32_t rpad;
+};
+static_assert(sizeof(DevPair) == 64, "DevPair is one 64-B line");
+
+struct alignas(16) DevTri {
+    float v0[3]; float e1x;
+    float e1y, e1z, e2x, e2y;
+    float e2z; int32_t mat; int32_t src; int32_t pad;   // src = index in the caller's triangle array
+};
+static_assert(sizeof(DevTri) == 48, "DevTri is three 16-B loads");
+
+struct alignas(16) DevInstance {
+    float inv[12];      // inverseTransform columns 0..3, rows 0..2: c0.xyz c1.xyz c2.xyz c3.xyz
+    float fwd[12];      // transform, same packing
+    float rootMin[3]; int32_t rootEnc;
+    float rootMax[3]; int32_t pairBase;
+    int32_t triBase;
+    int32_t flags;      // bit 0: BLAS is empty / invalid -> never hit
+    int32_t pad[2];
+};
+static_assert(sizeof(DevInstance) == 144, "DevInstance");
+
+struct TlasNode {       // == rz_bvh_node
+    float bmin[3]; int32_t leftFirst;
+    float bmax[3]; int32_t count;
+};
+
+struct DevMaterial { float albedo[3], metallic, roughness, reflectivity, transparency, ior; };
+struct DevLight { float posdir[4], color[3], power; };
+
+struct DevCounters {
+    unsigned long long samples, traversals, tlas_nodes, tlas_leaf_indices, instances, blas_nodes, triangles,
+        materials, light_fetches, pixels;
+};
+
+// Everything a render kernel needs, passed by value.
+struct KParams {
+    const DevPair* pairs;
+    const DevTri* tris;
+    const DevInstance* instances;
+    const TlasNode* tlasNodes;
+    const int32_t* tlasIndices;
+    const DevMaterial* materials;
+    const DevLight* lights;
+    float4* accum;          // width*height RGBA32F, row 0 = bottom
+    float* ior;             // width*height: FS:674's currentIor carried across rz_render calls
+    DevCounters* counters;  // only for the counting build
+    int32_t nTlasNodes;
+    int32_t nLights;        // min(numLights uniform, lights.length())  (FS:574-575)
+    int32_t nMaterials;
+    int32_t width, height;
+    int32_t tilesX, tilesY;
+    int32_t nLocalTiles;    // tiles owned by this context
+    int32_t tileRank, tileNRanks;
+    int32_t maxBounces;
+    int32_t spp, sampleBase;
+    int32_t blasStackCap;   // LDS entries per lane for the BLAS stack (>= max BLAS depth)
+    int32_t tlasStackCap;
+    float invView[16];
+    float invProj[16];
+    float camPos[3];
+};
+
+}  // namespace rz

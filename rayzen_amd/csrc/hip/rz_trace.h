@@ -1,0 +1,220 @@
+// rz_trace.h -- closest-hit query through TLAS and BLAS on gfx950.
+//
+// Computes exactly what FS:457-503 (traverseTLAS) / FS:419-454 (traverseBLAS)
+// / FS:391-416 (hitTriangle) / FS:380-388 (intersectAABB) compute -- same
+// float operations, same visiting order, same strict `t < tHit` tie rule --
+// but organised for the machine:
+//
+//  * BLAS: the shader pushes both children and tests each child's box when it
+//    is popped.  A box test is a pure function of (ray, box), so it is done
+//    here when the PARENT is expanded, on one aligned 64-B DevPair fetch that
+//    holds both children.  The shader pops the right child immediately after
+//    pushing it (nothing can change tHit in between), so the right child is
+//    continued into directly and only the left child is stacked -- and only
+//    if the ray hits its box -- together with its entry distance tmin, so the
+//    shader's `tmin > tHit` cull is re-evaluated against the CURRENT tHit
+//    when the entry is popped, without touching the node again.
+//    => one 64-B fetch per internal node instead of two 32-B node fetches per
+//       child, and a stack that holds at most one entry per tree level.
+//  * the BLAS stack lives in LDS, 8 B per entry, laid out [level][lane]:
+//    every lane of a wave addresses its own bank column, so pushes and pops
+//    are conflict-free at any mix of depths (ds_write_b64 / ds_read_b64,
+//    2 x 32-lane groups).  Capacity = the deepest BLAS of the scene, known on
+//    the host at upload time.
+//  * leaves index triangles gathered into leaf order (DevTri, 3 x 16-B loads,
+//    no index indirection); only (t, triangle id) are tracked while
+//    traversing -- hit point, normal and material are pure functions of the
+//    winner and are computed once at the end.
+#pragma once
+#include "rz_device_math.h"
+#include "rz_scene_dev.h"
+
+namespace rz {
+
+struct Tally {          // per-thread counts of the REFERENCE algorithm's memory touches
+    unsigned traversals, tlas_nodes, tlas_leaf_indices, instances, blas_nodes, triangles, materials, light_fetches,
+        samples;
+};
+
+struct HitRec {
+    float t;
+    v3 p;       // world-space hit point
+    v3 n;       // world-space geometric normal (unit)
+    int mat;
+    int inst;
+};
+
+// FS:380-388.  Returns the hit flag; tmin as the shader computes it.
+__device__ __forceinline__ bool slab(v3 o, v3 inv, float bx0, float by0, float bz0, float bx1, float by1, float bz1,
+                                     float& tmin) {
+    float t0x = (bx0 - o.x) * inv.x, t0y = (by0 - o.y) * inv.y, t0z = (bz0 - o.z) * inv.z;
+    float t1x = (bx1 - o.x) * inv.x, t1y = (by1 - o.y) * inv.y, t1z = (bz1 - o.z) * inv.z;
+    float sx = fmin_(t0x, t1x), sy = fmin_(t0y, t1y), sz = fmin_(t0z, t1z);
+    float gx = fmax_(t0x, t1x), gy = fmax_(t0y, t1y), gz = fmax_(t0z, t1z);
+    tmin = fmax_(fmax_(sx, sy), sz);
+    float tmax = fmin_(fmin_(gx, gy), gz);
+    return tmax >= fmax_(tmin, 0.0f);
+}
+
+// FS:391-416 without the outputs that are pure functions of (ray, t, triangle).
+// Evaluated without early exits: the accept decision is the conjunction of the
+// shader's tests in order, so values computed past a failed test are never used.
+__device__ __forceinline__ bool moller_trumbore(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float& t) {
+    v3 h = cross(d, e2);
+    float a = dot(e1, h);
+    float f = 1.0f / a;
+    v3 s = o - v0;
+    float u = f * dot(s, h);
+    v3 q = cross(s, e1);
+    float v = f * dot(d, q);
+    t = f * dot(e2, q);
+    bool ok = !(__builtin_fabsf(a) < 0.0001f);
+    ok = ok && !(u < 0.0f || u > 1.0f);
+    ok = ok && !(v < 0.0f || u + v > 1.0f);
+    return ok && (t > 0.0001f);
+}
+
+// 3x4 packed column-major transforms of DevInstance
+__device__ __forceinline__ v3 x34_point(const float* m, v3 v) {
+    return mk3(((m[0] * v.x + m[3] * v.y) + m[6] * v.z) + m[9],
+               ((m[1] * v.x + m[4] * v.y) + m[7] * v.z) + m[10],
+               ((m[2] * v.x + m[5] * v.y) + m[8] * v.z) + m[11]);
+}
+__device__ __forceinline__ v3 x34_dir(const float* m, v3 v) {
+    return mk3((m[0] * v.x + m[3] * v.y) + m[6] * v.z,
+               (m[1] * v.x + m[4] * v.y) + m[7] * v.z,
+               (m[2] * v.x + m[5] * v.y) + m[8] * v.z);
+}
+__device__ __forceinline__ v3 x34_normal(const float* m, v3 v) {   // mat3(transpose(m)) * v
+    return mk3((m[0] * v.x + m[1] * v.y) + m[2] * v.z,
+               (m[3] * v.x + m[4] * v.y) + m[5] * v.z,
+               (m[6] * v.x + m[7] * v.y) + m[8] * v.z);
+}
+
+// One instance's BLAS (FS:419-454) in the instance's local space.
+// bstk: this lane's column of the LDS stack, entries 64 apart.
+// Returns the winning triangle (absolute DevTri index) or -1; tLoc = its t.
+template <bool COUNT>
+__device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance* __restrict__ I, v3 lo, v3 ld,
+                                             float& tLocOut, uint2* bstk, Tally& c) {
+    float tLoc = 1e30f;
+    int best = -1;
+    const v3 inv = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+    if (COUNT) c.blas_nodes += 1;            // the shader pops the root
+    float tminRoot;
+    bool go = slab(lo, inv, I->rootMin[0], I->rootMin[1], I->rootMin[2], I->rootMax[0], I->rootMax[1], I->rootMax[2],
+                   tminRoot);
+    go = go && !(tminRoot > tLoc) && !(I->flags & 1);
+    int cur = I->rootEnc;
+    int sp = 0;
+    const DevPair* __restrict__ pairs = K.pairs + I->pairBase;
+    const DevTri* __restrict__ tris = K.tris + I->triBase;
+    while (go) {
+        if (cur < 0) {
+            // leaf: <= 4 triangles, contiguous in leaf order, tested in order
+            const int v = ~cur;
+            const int first = v >> 4, count = v & 15;
+            if (COUNT) c.triangles += (unsigned)count;
+            for (int i = 0; i < count; ++i) {
+                const float4* __restrict__ tp = reinterpret_cast<const float4*>(tris + first + i);
+                const float4 a = tp[0], b = tp[1], cc = tp[2];
+                float t;
+                if (moller_trumbore(lo, ld, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, cc.x), t)) {
+                    if (t < tLoc) { tLoc = t; best = first + i; }
+                }
+            }
+            // pop until an entry survives the cull against the current tLoc
+            go = false;
+            while (sp > 0) {
+                --sp;
+                const uint2 e = bstk[sp * 64];
+                if (__uint_as_float(e.y) > tLoc) continue;
+                cur = (int)e.x;
+                go = true;
+                break;
+            }
+        } else {
+            const float4* __restrict__ pp = reinterpret_cast<const float4*>(pairs + cur);
+            const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+            if (COUNT) c.blas_nodes += 2;        // the shader pushes, and later pops, both children
+            float tl, tr;
+            const bool hl = slab(lo, inv, p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, tl);
+            const bool hr = slab(lo, inv, p2.x, p2.y, p2.z, p3.x, p3.y, p3.z, tr);
+            if (hl) {
+                bstk[sp * 64] = make_uint2((unsigned)__float_as_int(p0.w), __float_as_uint(tl));
+                ++sp;
+            }
+            if (hr && !(tr > tLoc)) {
+                cur = __float_as_int(p2.w);
+            } else {
+                go = false;
+                while (sp > 0) {
+                    --sp;
+                    const uint2 e = bstk[sp * 64];
+                    if (__uint_as_float(e.y) > tLoc) continue;
+                    cur = (int)e.x;
+                    go = true;
+                    break;
+                }
+            }
+        }
+    }
+    tLocOut = tLoc;
+    return best < 0 ? -1 : best + I->triBase;
+}
+
+// FS:457-503.  tstk: this lane's column of the LDS TLAS stack (node ids).
+template <bool COUNT>
+__device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitRec& h, uint2* bstk, int* tstk,
+                                              Tally& c) {
+    float tHit = 1e30f;
+    int bestTri = -1, bestInst = -1;
+    v3 bestP = mk3(0.0f, 0.0f, 0.0f);
+    if (COUNT) c.traversals += 1;
+    const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int sp = 0;
+    if (K.nTlasNodes > 0) { tstk[0] = 0; sp = 1; }
+    while (sp > 0) {
+        --sp;
+        const int nidx = tstk[sp * 64];
+        const float4* __restrict__ np = reinterpret_cast<const float4*>(K.tlasNodes + nidx);
+        const float4 n0 = np[0], n1 = np[1];
+        if (COUNT) c.tlas_nodes += 1;
+        float tmin;
+        if (!slab(o, inv, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, tmin) || tmin > tHit) continue;
+        const int leftFirst = __float_as_int(n0.w), count = __float_as_int(n1.w);
+        if (count > 0) {
+            for (int i = 0; i < count; ++i) {
+                const int instIdx = K.tlasIndices[leftFirst + i];
+                const DevInstance* __restrict__ I = K.instances + instIdx;
+                if (COUNT) { c.tlas_leaf_indices += 1; c.instances += 1; }
+                const v3 lo = x34_point(I->inv, o);
+                const v3 ld = normalize(x34_dir(I->inv, d));
+                float tLoc;
+                const int tri = traverse_blas<COUNT>(K, I, lo, ld, tLoc, bstk, c);
+                if (tri >= 0) {
+                    const v3 localHit = lo + ld * tLoc;              // FS:410
+                    const v3 worldHit = x34_point(I->fwd, localHit); // FS:484
+                    const float tWorld = length(worldHit - o);       // FS:485
+                    if (tWorld < tHit) { tHit = tWorld; bestP = worldHit; bestTri = tri; bestInst = instIdx; }
+                }
+            }
+        } else if (count < 0 && sp + 2 <= K.tlasStackCap) {   // count == 0: the host builder's empty root
+            tstk[sp * 64] = leftFirst; ++sp;
+            tstk[sp * 64] = leftFirst + 1; ++sp;
+        }
+    }
+    if (bestTri < 0) return false;
+    // the winner's normal and material: FS:411-412, 489-491
+    const float4* __restrict__ tp = reinterpret_cast<const float4*>(K.tris + bestTri);
+    const float4 a = tp[0], b = tp[1], cc = tp[2];
+    const v3 ln = normalize(cross(mk3(a.w, b.x, b.y), mk3(b.z, b.w, cc.x)));
+    h.t = tHit;
+    h.p = bestP;
+    h.n = normalize(x34_normal(K.instances[bestInst].inv, ln));
+    h.mat = __float_as_int(cc.y);
+    h.inst = bestInst;
+    return true;
+}
+
+}  // namespace rz

@@ -1,0 +1,93 @@
+// Renderer.h -- the frontend-side glue: what RayZen's main.cpp does with
+// OpenGL, done with the C-ABI of include/rayzen_hip.h instead.  Header-only;
+// link the program with librayzen_host.so and librayzen_hip.so.
+//
+//   initializeSSBOs(scene)             <- main.cpp:897-1120  (build + 8x glBufferData)
+//   updateDynamicBVHAndSSBOs(scene)    <- main.cpp:1123-1208 (TLAS rebuild + glBufferSubData)
+//   sendSceneDataToShader(scene, ...)  <- main.cpp:1356-1392 (uniforms)
+//   draw() / finish()                  <- main.cpp:637 glDrawArrays / :1347 glFinish
+// Unlike the reference's per-frame path, updateDynamicBVHAndSSBOs re-uploads
+// only what changed (instances + TLAS, a few KB), not all geometry.
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "RayZenScene.h"
+#include "rayzen_hip.h"
+
+namespace rayzen {
+
+class Renderer {
+public:
+    explicit Renderer(int device = 0, unsigned flags = RZ_FLAG_NONE) : ctx_(rz_create(device, flags)) {
+        if (!ctx_) throw std::runtime_error(std::string("rz_create: ") + rz_last_error(nullptr));
+    }
+    ~Renderer() { rz_destroy(ctx_); }
+    Renderer(const Renderer&) = delete;
+    Renderer& operator=(const Renderer&) = delete;
+
+    void initializeSSBOs(const Scene& scene, bool shareMeshes = false) {
+        buffers_.build(scene, shareMeshes);
+        up(RZ_BIND_TRIANGLES, buffers_.allTriangles);
+        up(RZ_BIND_MATERIALS, scene.materials);
+        up(RZ_BIND_LIGHTS, scene.lights);
+        up(RZ_BIND_TLAS_NODES, buffers_.tlasNodes);
+        up(RZ_BIND_TLAS_INDICES, buffers_.tlasTriIndices);
+        up(RZ_BIND_BLAS_NODES, buffers_.allBLASNodes);
+        up(RZ_BIND_BLAS_INDICES, buffers_.allBLASTriIndices);
+        up(RZ_BIND_INSTANCES, buffers_.meshInstances);
+    }
+    void updateDynamicBVHAndSSBOs(const Scene& scene) {
+        buffers_.updateDynamic(scene);
+        // the TLAS keeps its node count (2*I-1) and index count (I) for a fixed instance count
+        upd(RZ_BIND_INSTANCES, buffers_.meshInstances);
+        upd(RZ_BIND_TLAS_NODES, buffers_.tlasNodes);
+        upd(RZ_BIND_TLAS_INDICES, buffers_.tlasTriIndices);
+    }
+    void sendSceneDataToShader(const Scene& scene, int width, int height, int bounceBudget, int spp = 1,
+                               int sampleBase = 0, int tileRank = 0, int tileNRanks = 1) {
+        rz_frame_params p{};
+        p.width = width; p.height = height;
+        mat4 iv = inverse(scene.camera.viewMatrix), ip = inverse(scene.camera.projectionMatrix);
+        std::memcpy(p.inv_view, iv.m, 64); std::memcpy(p.inv_proj, ip.m, 64);
+        std::memcpy(p.view, scene.camera.viewMatrix.m, 64); std::memcpy(p.proj, scene.camera.projectionMatrix.m, 64);
+        p.cam_pos[0] = scene.camera.position.x; p.cam_pos[1] = scene.camera.position.y; p.cam_pos[2] = scene.camera.position.z;
+        p.num_lights = (int)scene.lights.size();
+        p.bounce_budget = bounceBudget; p.spp = spp; p.sample_base = sampleBase;
+        p.tile_rank = tileRank; p.tile_nranks = tileNRanks;
+        check(rz_set_frame(ctx_, &p), "rz_set_frame");
+        width_ = width; height_ = height;
+    }
+    void draw() { check(rz_render(ctx_), "rz_render"); }
+    void finish() { check(rz_sync(ctx_), "rz_sync"); }
+    std::vector<float> readAccum() {
+        std::vector<float> out((size_t)width_ * height_ * 4);
+        check(rz_read_accum(ctx_, out.data(), out.size() * sizeof(float)), "rz_read_accum");
+        return out;
+    }
+    std::vector<uint8_t> resolveRGBA8() {
+        std::vector<uint8_t> out((size_t)width_ * height_ * 4);
+        check(rz_resolve_rgba8(ctx_, out.data(), out.size()), "rz_resolve_rgba8");
+        return out;
+    }
+    float lastRenderMs() { float ms = 0; int n = 0; check(rz_last_render_ms(ctx_, &ms, &n), "rz_last_render_ms"); return ms; }
+    rz_ctx* context() { return ctx_; }
+    const SceneBuffers& buffers() const { return buffers_; }
+
+private:
+    template <class T> void up(rz_binding b, const std::vector<T>& v) {
+        check(rz_upload(ctx_, b, v.data(), v.size() * sizeof(T)), "rz_upload");
+    }
+    template <class T> void upd(rz_binding b, const std::vector<T>& v) {
+        check(rz_update(ctx_, b, 0, v.data(), v.size() * sizeof(T)), "rz_update");
+    }
+    void check(int rc, const char* what) {
+        if (rc != RZ_OK) throw std::runtime_error(std::string(what) + ": " + rz_last_error(ctx_));
+    }
+    rz_ctx* ctx_;
+    SceneBuffers buffers_;
+    int width_ = 0, height_ = 0;
+};
+
+}  // namespace rayzen

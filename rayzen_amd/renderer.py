@@ -1,0 +1,140 @@
+"""Python view of the render C-ABI (include/rayzen_hip.h).
+
+`Renderer` is the analogue of what RayZen's main.cpp does around its draw
+call: upload the SSBO arrays (main.cpp:1072-1119), refresh the dynamic ones
+(main.cpp:1196-1207), send the per-frame uniforms (main.cpp:1356-1379), draw
+(main.cpp:637).  Everything it calls lives in librayzen_hip.so; there is no
+fallback path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .scene import BINDING_DTYPES, BIND_INSTANCES, BIND_TLAS_INDICES, BIND_TLAS_NODES
+
+
+class RayZenError(RuntimeError):
+    def __init__(self, what, code, message):
+        super().__init__(f"{what} failed ({code}): {message}")
+        self.code = code
+
+
+def frame_params(camera, width, height, num_lights, bounce_budget, spp, sample_base=0, tile_rank=0, tile_nranks=1):
+    p = _lib.FrameParams()
+    p.width, p.height = int(width), int(height)
+    p.inv_view[:] = camera.inv_view.tolist()
+    p.inv_proj[:] = camera.inv_proj.tolist()
+    p.view[:] = camera.view.tolist()
+    p.proj[:] = camera.proj.tolist()
+    p.cam_pos[:] = camera.position.tolist()
+    p.num_lights, p.bounce_budget = int(num_lights), int(bounce_budget)
+    p.spp, p.sample_base = int(spp), int(sample_base)
+    p.tile_rank, p.tile_nranks = int(tile_rank), int(tile_nranks)
+    return p
+
+
+class Renderer:
+    def __init__(self, device=0, flags=0):
+        self._L = _lib.hip()
+        self._c = self._L.rz_create(int(device), int(flags))
+        if not self._c:
+            raise RayZenError("rz_create", -2, self._L.rz_last_error(None).decode())
+        self.width = self.height = 0
+
+    def close(self):
+        c, self._c = getattr(self, "_c", None), None
+        if c:
+            self._L.rz_destroy(c)
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RayZenError(what, rc, self._L.rz_last_error(self._c).decode())
+
+    # -- glBufferData / glBufferSubData ------------------------------------
+    def upload(self, binding, array):
+        a = np.ascontiguousarray(array)
+        self._check(self._L.rz_upload(self._c, int(binding), a.ctypes.data if a.nbytes else None, a.nbytes), "rz_upload")
+
+    def update(self, binding, array, offset_bytes=0):
+        a = np.ascontiguousarray(array)
+        self._check(self._L.rz_update(self._c, int(binding), int(offset_bytes), a.ctypes.data if a.nbytes else None,
+                                      a.nbytes), "rz_update")
+
+    def upload_scene(self, scene):
+        """initializeSSBOs' eight uploads (main.cpp:1072-1119)."""
+        for b in BINDING_DTYPES:
+            self.upload(b, scene.arrays[b])
+
+    def update_dynamic(self, scene):
+        """The part of updateDynamicBVHAndSSBOs that changes per frame: instances + TLAS."""
+        for b in (BIND_INSTANCES, BIND_TLAS_NODES, BIND_TLAS_INDICES):
+            self.update(b, scene.arrays[b])
+
+    # -- uniforms + draw -----------------------------------------------------
+    def set_frame(self, params):
+        self._check(self._L.rz_set_frame(self._c, C.byref(params)), "rz_set_frame")
+        self.width, self.height = params.width, params.height
+
+    def set_stream(self, hip_stream):
+        self._check(self._L.rz_set_stream(self._c, C.c_void_p(hip_stream)), "rz_set_stream")
+
+    def bind_accum(self, device_ptr, nbytes):
+        self._check(self._L.rz_bind_accum(self._c, C.c_void_p(device_ptr), int(nbytes)), "rz_bind_accum")
+
+    def render(self):
+        self._check(self._L.rz_render(self._c), "rz_render")
+
+    def render_counted(self):
+        cnt = _lib.Counters()
+        self._check(self._L.rz_render_counted(self._c, C.byref(cnt)), "rz_render_counted")
+        return {n: int(getattr(cnt, n)) for n in _lib.COUNTER_FIELDS}
+
+    def sync(self):
+        self._check(self._L.rz_sync(self._c), "rz_sync")
+
+    def clear_accum(self):
+        self._check(self._L.rz_clear_accum(self._c), "rz_clear_accum")
+
+    def read_accum(self):
+        """(H, W, 4) float32; row 0 = bottom row; rgb = sum of per-sample radiance, a = sample count."""
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._L.rz_read_accum(self._c, out.ctypes.data, out.nbytes), "rz_read_accum")
+        return out
+
+    def resolve_rgba8(self):
+        out = np.empty((self.height, self.width, 4), np.uint8)
+        self._check(self._L.rz_resolve_rgba8(self._c, out.ctypes.data, out.nbytes), "rz_resolve_rgba8")
+        return out
+
+    def last_render_ms(self):
+        ms, n = C.c_float(0), C.c_int(0)
+        self._check(self._L.rz_last_render_ms(self._c, C.byref(ms), C.byref(n)), "rz_last_render_ms")
+        return float(ms.value), int(n.value)
+
+    def accum_device_ptr(self):
+        return self._L.rz_accum_device_ptr(self._c)
+
+    # -- convenience -----------------------------------------------------------
+    def render_scene(self, scene, width, height, spp, bounce_budget, num_lights=None, tile_rank=0, tile_nranks=1,
+                     chunk=None):
+        """Upload-free helper: set the frame for `scene.camera` and render spp samples (optionally in
+        chunks of `chunk` samples -- bit-identical to one call)."""
+        nl = len(scene.lights) if num_lights is None else num_lights
+        chunk = spp if not chunk else chunk
+        base = 0
+        while base < spp:
+            k = min(chunk, spp - base)
+            self.set_frame(frame_params(scene.camera, width, height, nl, bounce_budget, k, base, tile_rank, tile_nranks))
+            self.render()
+            base += k
+
+
+def algorithmic_bytes(c):
+    """the bytes RayZen's shader touches for these counts
+    (its SSBO element sizes: 32-B node, 4-B TLAS index, 144-B instance, 64-B triangle + 4-B index,
+    32-B material, 32-B light, 16-B RGBA32F pixel)."""
+    return (32 * c["tlas_nodes"] + 4 * c["tlas_leaf_indices"] + 144 * c["instances"] + 32 * c["blas_nodes"]
+            + 68 * c["triangles"] + 32 * c["materials"] + 32 * c["light_fetches"] + 16 * c["pixels"])

@@ -1,0 +1,317 @@
+"""Host-side scene assembly (Python view of rayzen_amd/csrc/host).
+
+Mirrors how RayZen's main.cpp builds its scene (RayZen/src/main.cpp:327-388):
+materials, lights, camera, meshes, GameObjects with a transform each, then
+`build()` = initializeSSBOs (main.cpp:941-1035) producing the six geometry
+arrays, and `update_dynamic()` = updateDynamicBVHAndSSBOs (main.cpp:1138-1194).
+All geometry work happens in librayzen_host.so (C++); this module only moves
+numpy arrays in and out.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+# SSBO element types (include/rayzen_hip.h; RayZen/include/{Mesh,BVH,Material,Light}.h)
+TRIANGLE = np.dtype([("v0", "<f4", 3), ("pad0", "<f4"), ("v1", "<f4", 3), ("pad1", "<f4"),
+                     ("v2", "<f4", 3), ("pad2", "<f4"), ("materialIndex", "<i4"), ("tail_pad", "<i4", 3)])
+BVH_NODE = np.dtype([("boundsMin", "<f4", 3), ("leftFirst", "<i4"), ("boundsMax", "<f4", 3), ("count", "<i4")])
+BVH_INSTANCE = np.dtype([("blasNodeOffset", "<i4"), ("blasTriOffset", "<i4"), ("meshIndex", "<i4"),
+                         ("globalTriOffset", "<i4"), ("transform", "<f4", 16), ("inverseTransform", "<f4", 16)])
+MATERIAL = np.dtype([("albedo", "<f4", 3), ("metallic", "<f4"), ("roughness", "<f4"),
+                     ("reflectivity", "<f4"), ("transparency", "<f4"), ("ior", "<f4")])
+LIGHT = np.dtype([("positionOrDirection", "<f4", 4), ("color", "<f4", 3), ("power", "<f4")])
+
+BIND_TRIANGLES, BIND_MATERIALS, BIND_LIGHTS = 0, 1, 2
+BIND_TLAS_NODES, BIND_TLAS_INDICES, BIND_BLAS_NODES, BIND_BLAS_INDICES, BIND_INSTANCES = 5, 6, 7, 8, 9
+BINDING_DTYPES = {BIND_TRIANGLES: TRIANGLE, BIND_MATERIALS: MATERIAL, BIND_LIGHTS: LIGHT,
+                  BIND_TLAS_NODES: BVH_NODE, BIND_TLAS_INDICES: np.dtype("<i4"), BIND_BLAS_NODES: BVH_NODE,
+                  BIND_BLAS_INDICES: np.dtype("<i4"), BIND_INSTANCES: BVH_INSTANCE}
+GEOMETRY_BINDINGS = (BIND_TRIANGLES, BIND_TLAS_NODES, BIND_TLAS_INDICES, BIND_BLAS_NODES, BIND_BLAS_INDICES,
+                     BIND_INSTANCES)
+
+
+def _p(a):
+    return a.ctypes.data
+
+
+def identity():
+    return np.eye(4, dtype=np.float32).reshape(16).copy()   # column-major == row-major for I
+
+
+def _mat_op(fn, m, *args):
+    m = np.ascontiguousarray(m, np.float32).reshape(16)
+    out = np.zeros(16, np.float32)
+    fn(_p(m), *args, _p(out))
+    return out
+
+
+def translate(m, v):
+    """glm::translate(m, v) = m * T(v); column-major 16 floats."""
+    v = np.asarray(v, np.float32).copy()
+    return _mat_op(_lib.host().rzh_mat_translate, m, _p(v))
+
+
+def scale(m, v):
+    v = np.asarray(v, np.float32).copy()
+    return _mat_op(_lib.host().rzh_mat_scale, m, _p(v))
+
+
+def rotate(m, angle, axis):
+    axis = np.asarray(axis, np.float32).copy()
+    m = np.ascontiguousarray(m, np.float32).reshape(16)
+    out = np.zeros(16, np.float32)
+    _lib.host().rzh_mat_rotate(_p(m), float(angle), _p(axis), _p(out))
+    return out
+
+
+def inverse(m):
+    m = np.ascontiguousarray(m, np.float32).reshape(16)
+    out = np.zeros(16, np.float32)
+    _lib.host().rzh_mat_inverse(_p(m), _p(out))
+    return out
+
+
+def load_obj(path, material_index):
+    """Mesh::loadFromOBJ (RayZen/src/Mesh.cpp:6-50)."""
+    import os
+    L = _lib.host()
+    p = os.fsencode(path)
+    n = L.rzh_load_obj(p, material_index, None, 0)
+    if n < 0:
+        raise FileNotFoundError(path)
+    tris = np.zeros(n, TRIANGLE)
+    L.rzh_load_obj(p, material_index, _p(tris), n)
+    return tris
+
+
+def make_cube(material_index):
+    tris = np.zeros(12, TRIANGLE)
+    _lib.host().rzh_make_cube(material_index, _p(tris), 12)
+    return tris
+
+
+def make_blob(n, radius, material_index, seed=1):
+    """Closed 12*n*n-triangle 'bunny' stand-in (include/rayzen_host.h)."""
+    total = 12 * n * n
+    tris = np.zeros(total, TRIANGLE)
+    got = _lib.host().rzh_make_blob(n, float(radius), seed, material_index, _p(tris), total)
+    assert got == total
+    return tris
+
+
+def make_quad(p0, p1, p2, p3, material_index):
+    """Two triangles (p0,p1,p2), (p0,p2,p3)."""
+    t = np.zeros(2, TRIANGLE)
+    t["v0"][0], t["v1"][0], t["v2"][0] = p0, p1, p2
+    t["v0"][1], t["v1"][1], t["v2"][1] = p0, p2, p3
+    t["materialIndex"] = material_index
+    return t
+
+
+def build_blas(tris):
+    """BVH::buildBLAS (RayZen/src/BVH.cpp:99-175). Returns (nodes, indices, depth)."""
+    tris = np.ascontiguousarray(tris)
+    assert tris.dtype.itemsize == 64
+    n = tris.shape[0]
+    nodes = np.zeros(2 * max(n, 1) + 1, BVH_NODE)
+    idx = np.zeros(max(n, 1), np.int32)
+    depth = C.c_int(0)
+    nn = _lib.host().rzh_build_blas(_p(tris) if n else None, n, _p(nodes), _p(idx), C.byref(depth))
+    if nn < 0:
+        raise RuntimeError("rzh_build_blas failed")
+    return nodes[:nn].copy(), idx[:n].copy(), depth.value
+
+
+def build_tlas(world_roots):
+    r = np.ascontiguousarray(world_roots)
+    assert r.dtype.itemsize == 32
+    n = r.shape[0]
+    nodes = np.zeros(2 * max(n, 1), BVH_NODE)
+    idx = np.zeros(max(n, 1), np.int32)
+    ni = C.c_int(0)
+    nn = _lib.host().rzh_build_tlas(_p(r) if n else None, n, _p(nodes), _p(idx), C.byref(ni))
+    if nn < 0:
+        raise RuntimeError("rzh_build_tlas failed")
+    return nodes[:nn].copy(), idx[:ni.value].copy()
+
+
+# RayZen's materials (main.cpp:342-353) and lights (main.cpp:356-357)
+def reference_materials():
+    m = np.zeros(5, MATERIAL)
+    rows = [((0.8, 0.3, 0.3), 0.0, 1.0, 0.0, 0.0, 1.5),      # 0 red matte
+            ((0.1, 0.7, 0.1), 1.0, 0.35, 0.3, 0.0, 1.5),     # 1 green metallic
+            ((1.0, 1.0, 1.0), 1.0, 0.05, 1.0, 0.0, 1.5),     # 2 mirror
+            ((0.85, 0.95, 1.0), 0.0, 0.02, 0.05, 0.94, 1.5),  # 3 glass
+            ((0.6, 0.4, 0.2), 0.0, 0.9, 0.2, 0.0, 1.5)]      # 4 rough
+    for i, (alb, met, rough, refl, transp, ior) in enumerate(rows):
+        m[i] = (alb, met, rough, refl, transp, ior)
+    return m
+
+
+def reference_lights():
+    l = np.zeros(2, LIGHT)
+    l[0] = ((5.0, 5.0, 5.0, 1.0), (1.0, 1.0, 1.0), 300.0)   # point light
+    l[1] = ((0.8, 1.4, 0.3, 0.0), (1.0, 1.0, 1.0), 2.0)     # directional
+    return l
+
+
+class Camera:
+    """include/Camera.h: position, target (a direction), up, fov in degrees."""
+
+    def __init__(self, position=(0.0, 0.0, 3.0), target=(0.0, 0.0, -1.0), up=(0.0, 1.0, 0.0), fov=70.0,
+                 aspect=800.0 / 600.0, near=0.1, far=100.0):
+        self.position = np.asarray(position, np.float32).copy()
+        self.target = np.asarray(target, np.float32).copy()
+        self.up = np.asarray(up, np.float32).copy()
+        self.fov, self.aspect, self.near, self.far = float(fov), float(aspect), float(near), float(far)
+        self.update()
+
+    def update(self):
+        self.view, self.proj = np.zeros(16, np.float32), np.zeros(16, np.float32)
+        self.inv_view, self.inv_proj = np.zeros(16, np.float32), np.zeros(16, np.float32)
+        _lib.host().rzh_camera_matrices(_p(self.position), _p(self.target), _p(self.up), self.fov, self.aspect,
+                                        self.near, self.far, _p(self.view), _p(self.proj), _p(self.inv_view),
+                                        _p(self.inv_proj))
+
+
+class Scene:
+    """Scene + its SSBO arrays.  `arrays` maps binding index -> numpy array."""
+
+    def __init__(self, materials=None, lights=None, camera=None):
+        self._h = _lib.host().rzh_scene_create()
+        if not self._h:
+            raise MemoryError("rzh_scene_create")
+        self.materials = reference_materials() if materials is None else np.ascontiguousarray(materials)
+        self.lights = reference_lights() if lights is None else np.ascontiguousarray(lights)
+        self.camera = camera or Camera()
+        self.arrays = {}
+        self.max_blas_depth = self.tlas_depth = 0
+        self.name = ""
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.host().rzh_scene_destroy(h)
+
+    def add_mesh(self, tris):
+        tris = np.ascontiguousarray(tris)
+        assert tris.dtype.itemsize == 64
+        mid = _lib.host().rzh_scene_add_mesh(self._h, _p(tris) if tris.shape[0] else None, tris.shape[0])
+        if mid < 0:
+            raise RuntimeError("rzh_scene_add_mesh failed")
+        return mid
+
+    def add_object(self, mesh_id, transform=None):
+        t = identity() if transform is None else np.ascontiguousarray(transform, np.float32).reshape(16)
+        oid = _lib.host().rzh_scene_add_object(self._h, mesh_id, _p(t))
+        if oid < 0:
+            raise RuntimeError("rzh_scene_add_object failed")
+        return oid
+
+    def set_transform(self, object_id, transform):
+        t = np.ascontiguousarray(transform, np.float32).reshape(16)
+        if _lib.host().rzh_scene_set_transform(self._h, object_id, _p(t)) != 0:
+            raise RuntimeError("rzh_scene_set_transform failed")
+
+    def _pull(self, bindings):
+        L = _lib.host()
+        for b in bindings:
+            nbytes = C.c_size_t(0)
+            ptr = L.rzh_scene_buffer(self._h, b, C.byref(nbytes))
+            dt = BINDING_DTYPES[b]
+            n = nbytes.value // dt.itemsize
+            if n:
+                buf = (C.c_char * nbytes.value).from_address(ptr)
+                self.arrays[b] = np.frombuffer(buf, dtype=dt, count=n).copy()
+            else:
+                self.arrays[b] = np.zeros(0, dt)
+        self.arrays[BIND_MATERIALS] = self.materials
+        self.arrays[BIND_LIGHTS] = self.lights
+        bd, td = C.c_int(0), C.c_int(0)
+        L.rzh_scene_depths(self._h, C.byref(bd), C.byref(td))
+        self.max_blas_depth, self.tlas_depth = bd.value, td.value
+
+    def build(self, share_meshes=False):
+        if _lib.host().rzh_scene_build(self._h, 1 if share_meshes else 0) != 0:
+            raise RuntimeError("rzh_scene_build failed")
+        self._pull(GEOMETRY_BINDINGS)
+        return self
+
+    def update_dynamic(self):
+        if _lib.host().rzh_scene_update_dynamic(self._h) != 0:
+            raise RuntimeError("rzh_scene_update_dynamic failed")
+        self._pull((BIND_INSTANCES, BIND_TLAS_NODES, BIND_TLAS_INDICES))
+        return self
+
+
+# --------------------------------------------------------------------------
+# The benchmark / parity configurations of BASELINE.json.
+# No asset file is needed: the "bunny" is the procedural blob of rzh_make_blob.
+# --------------------------------------------------------------------------
+
+def cornell_scene():
+    """C1: floor quad + back-wall quad + cube = 16 triangles, 3 instances."""
+    s = Scene(camera=Camera(position=(0.0, 0.5, 4.5), aspect=1.0))
+    floor = s.add_mesh(make_quad((-4, -1.5, 4), (4, -1.5, 4), (4, -1.5, -4), (-4, -1.5, -4), 4))
+    wall = s.add_mesh(make_quad((-4, -1.5, -3), (4, -1.5, -3), (4, 4.5, -3), (-4, 4.5, -3), 1))
+    cube = s.add_mesh(make_cube(0))
+    s.add_object(floor)
+    s.add_object(wall)
+    s.add_object(cube, rotate(translate(identity(), (0.3, -0.5, 0.0)), 0.6, (0.0, 1.0, 0.0)))
+    s.name = "cornell16"
+    return s.build()
+
+
+def bunny_scene(n=76, aspect=16.0 / 9.0, bunny_material=0, floor_material=4, extras=False, radius=2.8):
+    """C2/C3: ~69k-triangle closed mesh ('bunny' stand-in, 12*n*n triangles) over the reference's floor.
+
+    extras adds a glass blob and a mirror cube so every material branch is exercised."""
+    s = Scene(camera=Camera(position=(0.0, 2.5, 10.0), aspect=aspect))
+    floor = s.add_mesh(make_cube(floor_material))
+    bunny = s.add_mesh(make_blob(n, radius, bunny_material))
+    # main.cpp:378: translate(scale(I, (8, .5, 8)), (0, -3, 0))
+    s.add_object(floor, translate(scale(identity(), (8.0, 0.5, 8.0)), (0.0, -3.0, 0.0)))
+    s.add_object(bunny, translate(identity(), (0.0, 2.0, 0.0)))
+    if extras:
+        glass = s.add_mesh(make_blob(max(4, n // 4), 1.2, 3, seed=7))
+        mirror = s.add_mesh(make_cube(2))
+        s.add_object(glass, translate(identity(), (4.5, 0.6, 3.0)))
+        s.add_object(mirror, rotate(translate(identity(), (-5.0, 0.0, 1.5)), 0.5, (0.0, 1.0, 0.0)))
+    s.name = f"bunny{12 * n * n}" + ("+glass+mirror" if extras else "")
+    return s.build()
+
+
+def instanced_transforms(frame, count=16, spacing=3.0, obj_scale=0.4):
+    """C4: 4x4 grid, transform_i(frame) = translate * rotateY(0.1*frame + i) * scale."""
+    side = int(round(count ** 0.5))
+    out = []
+    for i in range(count):
+        gx, gz = i % side, i // side
+        t = translate(identity(), ((gx - (side - 1) / 2.0) * spacing, 0.4, (gz - (side - 1) / 2.0) * spacing))
+        t = rotate(t, 0.1 * frame + i, (0.0, 1.0, 0.0))
+        out.append(scale(t, (obj_scale, obj_scale, obj_scale)))
+    return out
+
+
+def instanced_scene(n=76, count=16, aspect=16.0 / 9.0, share_meshes=True):
+    """C4: `count` instances of the bunny mesh over the floor; per-frame TLAS rebuild via set_transform + update_dynamic."""
+    s = Scene(camera=Camera(position=(0.0, 5.0, 12.0), target=(0.0, -0.35, -1.0), aspect=aspect))
+    floor = s.add_mesh(make_cube(4))
+    bunny = s.add_mesh(make_blob(n, 2.8, 0))
+    s.add_object(floor, translate(scale(identity(), (8.0, 0.5, 8.0)), (0.0, -3.0, 0.0)))
+    s.instance_ids = [s.add_object(bunny, t) for t in instanced_transforms(0, count)]
+    s.name = f"instanced{count}x{12 * n * n}"
+    return s.build(share_meshes=share_meshes)
+
+
+def stress_scene(n=289, aspect=16.0 / 9.0):
+    """C5: ~1M-triangle blob, radius 10."""
+    s = Scene(camera=Camera(position=(0.0, 6.0, 34.0), aspect=aspect))
+    floor = s.add_mesh(make_cube(4))
+    blob = s.add_mesh(make_blob(n, 10.0, 0))
+    s.add_object(floor, translate(scale(identity(), (40.0, 0.5, 40.0)), (0.0, -28.0, 0.0)))
+    s.add_object(blob, identity())
+    s.name = f"stress{12 * n * n}"
+    return s.build()
