@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the path-tracing render loop on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one frame of synthetic input: BASELINE.json configs[1],
+the ~69k-triangle "bunny" scene (procedural stand-in, see rayzen_amd/scene.py) at 1920x1080,
+4 bounces, 64 samples per pixel per GPU.  At N > 1 the frame's 8x8-pixel tiles are dealt round-robin
+to the ranks, every rank renders 64*N spp of its own pixels (per-GPU work is constant: weak scaling),
+and one RCCL reduce(SUM) per step lands the frame on rank 0 (rayzen_amd/dist.py).  Scene buffers are
+resident in HBM before the timed region; nothing is skipped inside it.
+
+Rank 0 prints ONE JSON line.  `value` = total camera paths (pixels x spp) of all ranks / wall time of
+the K timed steps (max over ranks).  `roofline` prices the render kernel: `achieved` = algorithmic
+bytes per launch (the bytes RayZen's shader would read from its SSBOs for exactly this frame, counted
+by an untimed instrumented launch) / the kernel's mean duration measured with HIP
+events on its stream.  `cpu_baseline` = the oracle (a CPU port of the same path) timed on a bounded
+sample of the same frame, which doubles as a full-size parity check of those pixels.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    # workload overrides (the defaults ARE the BASELINE config; anything else is for development)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per GPU")
+    ap.add_argument("--bounces", type=int, default=4)
+    ap.add_argument("--mesh-n", type=int, default=76, help="bunny stand-in has 12*n*n triangles")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (default: min(16, usable cores) = the box's CPU share)")
+    ap.add_argument("--cpu-bands", type=int, default=18, help="oracle sample: this many 8-row bands of the frame")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from rayzen_amd import scene as S
+    from rayzen_amd import dist as rzdist
+    from rayzen_amd.renderer import Renderer, algorithmic_bytes, frame_params
+
+    W, H, bounces = a.width, a.height, a.bounces
+    spp_total = a.spp * world          # every rank renders ALL samples of its own pixels
+    sc = S.bunny_scene(n=a.mesh_n, aspect=W / H)
+    r = Renderer(local_rank)
+    r.upload_scene(sc)
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)    # zero outside this rank's tiles
+    stream = torch.cuda.Stream(dev)     # the kernels, the reduce and the fences all order on this stream
+    torch.cuda.set_stream(stream)
+    r.set_stream(stream.cuda_stream)
+    r.bind_accum(accum.data_ptr(), accum.numel() * 4)
+    fp = frame_params(sc.camera, W, H, len(sc.lights), bounces, spp_total, 0, rank, world)
+    r.set_frame(fp)
+
+    def step():
+        r.render()                      # async on torch's current stream
+        if world > 1:
+            rzdist.reduce_accum(accum, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # untimed instrumented launch: exact algorithmic bytes of THIS rank's launch
+    counters = r.render_counted()
+    alg_bytes = algorithmic_bytes(counters)
+    torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    r.render_history_ms()               # drain: only the timed launches remain in the event ring
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    # GPU duration of each timed launch: HIP event pairs recorded on the launch stream inside the timed region
+    kernel_ms = r.render_history_ms()
+    kms = float(np.mean(kernel_ms))
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_samples = W * H * spp_total * a.steps
+    value = total_samples / elapsed / 1e6
+
+    out = {
+        "metric": "Msamples/s (rays x spp / s) at 1080p", "value": round(value, 3), "unit": "Msamples/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[1]: bunny stand-in ({sc.name}, {sc.arrays[S.BIND_TRIANGLES].shape[0]} tris "
+                               f"incl. floor) {W}x{H}, {a.spp} spp per GPU ({spp_total} spp total), {bounces} bounces, "
+                               f"2 lights", "width": W, "height": H, "spp_per_gpu": a.spp, "spp_total": spp_total,
+                   "bounces": bounces, "triangles": int(sc.arrays[S.BIND_TRIANGLES].shape[0]),
+                   "parallelism": f"tiles8x8-roundrobin-x{world}" + ("+rccl-reduce" if world > 1 else "")},
+    }
+    if rank == 0:
+        ach = alg_bytes / (kms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath) and world == 1:
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == [W, H, a.spp, bounces, a.mesh_n]:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                           "kernel": "rz_render_pixels", "kernel_ms": round(kms, 3),
+                           "algorithmic_bytes_per_launch": int(alg_bytes),
+                           "algorithmic_bytes_per_sample": round(alg_bytes / max(counters["samples"], 1), 1),
+                           "kernel_msamples_per_s": round(counters["samples"] / (kms * 1e-3) / 1e6, 2)}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import rzo
+        from helpers import oracle_frame, oracle_scene
+        ncores = a.cpu_threads if a.cpu_threads > 0 else min(16, len(os.sched_getaffinity(0)))
+        osc = oracle_scene(sc)
+        ofr = oracle_frame(sc, W, H, a.spp, bounces)
+        ref = np.zeros((H, W, 4), np.float32)
+        nb = max(1, a.cpu_bands)
+        rows = 0
+        t_cpu = 0.0
+        bands = []
+        for b in range(nb):
+            y0 = min(H - 8, int((b + 0.5) * H / nb) // 8 * 8)
+            tc = time.perf_counter()
+            rzo.render(osc, ofr, accum=ref, crop=(0, y0, W, y0 + 8), nthreads=ncores)
+            t_cpu += time.perf_counter() - tc
+            rows += 8
+            bands.append(y0)
+        cpu_samples = rows * W * a.spp
+        gpu = accum.cpu().numpy()       # last timed frame (sample_base 0 each step: a complete frame)
+        err = 0.0
+        same = 0
+        tot = 0
+        for y0 in bands:
+            g, o = gpu[y0:y0 + 8], ref[y0:y0 + 8]
+            err = max(err, float(np.abs(g.astype(np.float64) - o.astype(np.float64)).max()))
+            same += int((g.view(np.uint32) == o.view(np.uint32)).all(axis=-1).sum())
+            tot += g.shape[0] * g.shape[1]
+        out["cpu_baseline"] = {"value": round(cpu_samples / t_cpu / 1e6, 4), "unit": "Msamples/s", "cores": ncores,
+                               "kind": "port",
+                               "sample": f"{nb} full-width 8-row bands of the same {W}x{H}x{a.spp}spp frame "
+                                         f"({cpu_samples} of {W * H * a.spp} camera paths, {t_cpu:.1f} s)",
+                               "gpu_over_cpu": round(value / (cpu_samples / t_cpu / 1e6), 1)}
+        out["parity"] = {"linf_vs_oracle_on_sample": err, "bit_identical_pixels": same, "pixels_compared": tot}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -208,6 +208,11 @@ int rz_resolve_rgba8(rz_ctx* ctx, uint8_t* rgba8, size_t bytes);
  * rz_render spent on the GPU (HIP events on the stream they ran on), and how
  * many kernel launches that was.  Synchronises. */
 int rz_last_render_ms(rz_ctx* ctx, float* ms, int* launches);
+/* Every rz_render launch is bracketed by a HIP event pair on its stream (a ring of 64).  Copies the
+ * durations (ms, oldest first) of the launches issued since the previous call -- at most `cap`,
+ * at most 64 -- and returns how many; negative on error.  Synchronises on those events only, so a
+ * timed loop can issue its launches back to back and collect their GPU times afterwards. */
+int rz_render_history_ms(rz_ctx* ctx, float* ms, int cap);
 
 /* Device pointer of the accumulation buffer currently in use. */
 void* rz_accum_device_ptr(rz_ctx* ctx);

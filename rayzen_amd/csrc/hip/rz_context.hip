@@ -73,7 +73,12 @@ struct rz_ctx {
     unsigned flags = 0;
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t evStart = nullptr, evStop = nullptr;
+    // a ring of event pairs: every render launch is bracketed on its stream, and the durations can be
+    // collected later without synchronising inside a timed loop
+    static constexpr int kRing = 64;
+    hipEvent_t evStart[kRing] = {}, evStop[kRing] = {};
+    int ringHead = 0;       // next slot to record into
+    int ringCount = 0;      // launches recorded since the history was last drained (<= kRing)
     bool timed = false;
     int lastLaunches = 0;
     std::string err;
@@ -388,10 +393,13 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
         RZ_HIP(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(DevCounters), c->stream));
         K.counters = static_cast<DevCounters*>(c->dCounters.p);
     }
-    RZ_HIP(c, hipEventRecord(c->evStart, c->stream));
+    const int slot = c->ringHead;
+    RZ_HIP(c, hipEventRecord(c->evStart[slot], c->stream));
     launch_render_pixels(K, counted, c->stream);
     RZ_HIP(c, hipGetLastError());
-    RZ_HIP(c, hipEventRecord(c->evStop, c->stream));
+    RZ_HIP(c, hipEventRecord(c->evStop[slot], c->stream));
+    c->ringHead = (slot + 1) % rz_ctx::kRing;
+    c->ringCount = std::min(c->ringCount + 1, (int)rz_ctx::kRing);
     c->timed = true;
     c->lastLaunches = 1;
     if (counted && out) {
@@ -436,10 +444,13 @@ rz_ctx* rz_create(int device, unsigned flags) {
     if (!c) { fail(nullptr, RZ_ERR_HIP, "out of host memory"); return nullptr; }
     c->device = device;
     c->flags = flags;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->evStart) != hipSuccess || hipEventCreate(&c->evStop) != hipSuccess) {
+    bool ok = hipSetDevice(device) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < rz_ctx::kRing; ++i)
+        ok = hipEventCreate(&c->evStart[i]) == hipSuccess && hipEventCreate(&c->evStop[i]) == hipSuccess;
+    if (!ok) {
         fail(nullptr, RZ_ERR_HIP, "cannot create stream/events on device %d", device);
-        delete c;
+        rz_destroy(c);
         return nullptr;
     }
     c->stream = c->ownStream;
@@ -449,12 +460,14 @@ rz_ctx* rz_create(int device, unsigned flags) {
 void rz_destroy(rz_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
                       &c->dCounters, &c->dResolve, &c->ownAccum, &c->dIor})
         b->release();
-    if (c->evStart) (void)hipEventDestroy(c->evStart);
-    if (c->evStop) (void)hipEventDestroy(c->evStop);
+    for (int i = 0; i < rz_ctx::kRing; ++i) {
+        if (c->evStart[i]) (void)hipEventDestroy(c->evStart[i]);
+        if (c->evStop[i]) (void)hipEventDestroy(c->evStop[i]);
+    }
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
 }
@@ -595,12 +608,26 @@ int rz_resolve_rgba8(rz_ctx* c, uint8_t* rgba8, size_t bytes) {
 int rz_last_render_ms(rz_ctx* c, float* ms, int* launches) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
     if (!c->timed) return fail(c, RZ_ERR_NOT_READY, "nothing rendered yet");
-    RZ_HIP(c, hipEventSynchronize(c->evStop));
+    const int slot = (c->ringHead + rz_ctx::kRing - 1) % rz_ctx::kRing;
+    RZ_HIP(c, hipEventSynchronize(c->evStop[slot]));
     float t = 0.0f;
-    RZ_HIP(c, hipEventElapsedTime(&t, c->evStart, c->evStop));
+    RZ_HIP(c, hipEventElapsedTime(&t, c->evStart[slot], c->evStop[slot]));
     if (ms) *ms = t;
     if (launches) *launches = c->lastLaunches;
     return RZ_OK;
+}
+
+int rz_render_history_ms(rz_ctx* c, float* ms, int cap) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    if (cap < 0 || (cap > 0 && !ms)) return fail(c, RZ_ERR_INVALID_ARG, "bad history buffer");
+    const int n = std::min(c->ringCount, cap);
+    for (int i = 0; i < n; ++i) {     // oldest of the last n first
+        const int slot = (c->ringHead + 2 * rz_ctx::kRing - n + i) % rz_ctx::kRing;
+        RZ_HIP(c, hipEventSynchronize(c->evStop[slot]));
+        RZ_HIP(c, hipEventElapsedTime(&ms[i], c->evStart[slot], c->evStop[slot]));
+    }
+    c->ringCount = 0;
+    return n;
 }
 
 }  // extern "C"

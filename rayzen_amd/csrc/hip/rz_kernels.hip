@@ -17,9 +17,12 @@
 namespace rz {
 
 constexpr int WAVES_PER_BLOCK = 4;
+#ifndef RZ_MIN_WAVES_PER_SIMD
+#define RZ_MIN_WAVES_PER_SIMD 2
+#endif
 
 template <bool COUNT>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void rz_render_pixels(const KParams K) {
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void rz_render_pixels(const KParams K) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;

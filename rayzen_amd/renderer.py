@@ -114,6 +114,14 @@ class Renderer:
         self._check(self._L.rz_last_render_ms(self._c, C.byref(ms), C.byref(n)), "rz_last_render_ms")
         return float(ms.value), int(n.value)
 
+    def render_history_ms(self, cap=64):
+        """GPU durations (ms) of the render launches issued since the previous call (oldest first)."""
+        buf = (C.c_float * cap)()
+        n = self._L.rz_render_history_ms(self._c, buf, cap)
+        if n < 0:
+            self._check(n, "rz_render_history_ms")
+        return [float(buf[k]) for k in range(n)]
+
     def accum_device_ptr(self):
         return self._L.rz_accum_device_ptr(self._c)
 
