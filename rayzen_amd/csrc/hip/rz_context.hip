@@ -388,9 +388,9 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     if (perWave * 4 > 160 * 1024)
         return fail(c, RZ_ERR_BAD_SCENE, "BLAS depth %d needs %zu B of LDS stack per wave; the limit is %d", c->maxBlasDepth, perWave, 40 * 1024);
     if (counted) {
-        rc = ensure(c, c->dCounters, sizeof(DevCounters));
+        rc = ensure(c, c->dCounters, sizeof(DevCounters) + 32 * sizeof(unsigned long long));
         if (rc != RZ_OK) return rc;
-        RZ_HIP(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(DevCounters), c->stream));
+        RZ_HIP(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(DevCounters) + 32 * sizeof(unsigned long long), c->stream));
         K.counters = static_cast<DevCounters*>(c->dCounters.p);
     }
     const int slot = c->ringHead;
@@ -410,6 +410,14 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
         out->tlas_leaf_indices = h.tlas_leaf_indices; out->instances = h.instances; out->blas_nodes = h.blas_nodes;
         out->triangles = h.triangles; out->materials = h.materials; out->light_fetches = h.light_fetches;
         out->pixels = h.pixels;
+#ifdef RZ_PROF
+        unsigned long long pr[32];
+        RZ_HIP(c, hipMemcpy(pr, static_cast<char*>(c->dCounters.p) + sizeof(DevCounters), sizeof pr, hipMemcpyDeviceToHost));
+        static const char* names[] = {"blas loop iter", "leaf branch", "triangle test", "internal branch", "tlas pop", "instance enter", "outer iter", "begin_sample"};
+        for (int k = 0; k < 8; ++k)
+            fprintf(stderr, "[rz_prof] %-16s wave-execs %12llu  lanes %14llu  avg active lanes %.1f\n", names[k], pr[2 * k], pr[2 * k + 1], pr[2 * k] ? (double)pr[2 * k + 1] / (double)pr[2 * k] : 0.0);
+        fprintf(stderr, "[rz_prof] wave cycles: begin %llu  trace %llu  advance %llu\n", pr[16], pr[17], pr[18]);
+#endif
     }
     return RZ_OK;
 }

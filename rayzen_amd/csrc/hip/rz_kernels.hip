@@ -61,12 +61,35 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
             P.ior = K.ior[pix];
         }
     }
+#ifdef RZ_PROF
+    unsigned long long tTrace = 0, tAdv = 0, tBegin = 0;
+#endif
     while (P.samp < P.sampEnd) {
+#ifdef RZ_PROF
+        RZ_SITE(c, 6);
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        if (P.mode == MODE_DONE) { RZ_SITE(c, 7); begin_sample<COUNT>(K, P, c); }
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        HitRec h;
+        const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, c);
+        unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        advance<COUNT>(K, P, found, h, c);
+        unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        tBegin += t1 - t0; tTrace += t2 - t1; tAdv += t3 - t2;
+#else
         if (P.mode == MODE_DONE) begin_sample<COUNT>(K, P, c);
         HitRec h;
         const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, c);
         advance<COUNT>(K, P, found, h, c);
+#endif
     }
+#ifdef RZ_PROF
+    if (COUNT) {
+        unsigned long long* pr = reinterpret_cast<unsigned long long*>(K.counters + 1);
+        for (int k = 0; k < 16; ++k) atomicAdd(&pr[k], (unsigned long long)c.p[k]);
+        if (lane == 0) { atomicAdd(&pr[16], tBegin); atomicAdd(&pr[17], tTrace); atomicAdd(&pr[18], tAdv); }
+    }
+#endif
     if (inside) {
         K.accum[pix] = make_float4(P.color.x, P.color.y, P.color.z, alpha + (float)K.spp);
         K.ior[pix] = P.ior;

@@ -31,10 +31,23 @@
 
 namespace rz {
 
+#ifndef RZ_DESCEND_MIN_LANES
+#define RZ_DESCEND_MIN_LANES 8   // leave the descend loop when fewer lanes than this still have an internal node (measured: 1 -> 125 ms, 8 -> 99 ms, 16 -> 105 ms on C2)
+#endif
+
 struct Tally {          // per-thread counts of the REFERENCE algorithm's memory touches
     unsigned traversals, tlas_nodes, tlas_leaf_indices, instances, blas_nodes, triangles, materials, light_fetches,
         samples;
+#ifdef RZ_PROF          // diagnostic build only: where do the lanes of a wave spend their iterations?
+    unsigned p[16];
+#endif
 };
+#ifdef RZ_PROF
+// slot 2k counts wave-level executions of a site (added by the first active lane), slot 2k+1 the active lanes
+#define RZ_SITE(c, k) do { (c).p[2 * (k) + 1] += 1u; if (__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) (c).p[2 * (k)] += 1u; } while (0)
+#else
+#define RZ_SITE(c, k) do { } while (0)
+#endif
 
 struct HitRec {
     float t;
@@ -109,31 +122,13 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
     int sp = 0;
     const DevPair* __restrict__ pairs = K.pairs + I->pairBase;
     const DevTri* __restrict__ tris = K.tris + I->triBase;
+    // "while-while": the inner loop walks internal nodes; a lane that reaches a leaf parks there (its own
+    // sequence of operations is unchanged) until the lanes of the wave still descending are few, then the
+    // parked lanes test their leaves together.  Without this the wave ran the triangle tests for ~7 of its
+    // 64 lanes at a time.
     while (go) {
-        if (cur < 0) {
-            // leaf: <= 4 triangles, contiguous in leaf order, tested in order
-            const int v = ~cur;
-            const int first = v >> 4, count = v & 15;
-            if (COUNT) c.triangles += (unsigned)count;
-            for (int i = 0; i < count; ++i) {
-                const float4* __restrict__ tp = reinterpret_cast<const float4*>(tris + first + i);
-                const float4 a = tp[0], b = tp[1], cc = tp[2];
-                float t;
-                if (moller_trumbore(lo, ld, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, cc.x), t)) {
-                    if (t < tLoc) { tLoc = t; best = first + i; }
-                }
-            }
-            // pop until an entry survives the cull against the current tLoc
-            go = false;
-            while (sp > 0) {
-                --sp;
-                const uint2 e = bstk[sp * 64];
-                if (__uint_as_float(e.y) > tLoc) continue;
-                cur = (int)e.x;
-                go = true;
-                break;
-            }
-        } else {
+        while (go && cur >= 0) {
+            RZ_SITE(c, 3);
             const float4* __restrict__ pp = reinterpret_cast<const float4*>(pairs + cur);
             const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
             if (COUNT) c.blas_nodes += 2;        // the shader pushes, and later pops, both children
@@ -157,7 +152,35 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
                     break;
                 }
             }
+            if (__popcll(__ballot(go && cur >= 0)) < RZ_DESCEND_MIN_LANES) break;
         }
+        if (go && cur < 0) {
+            RZ_SITE(c, 1);
+            // leaf: <= 4 triangles, contiguous in leaf order, tested in order
+            const int v = ~cur;
+            const int first = v >> 4, count = v & 15;
+            if (COUNT) c.triangles += (unsigned)count;
+            for (int i = 0; i < count; ++i) {
+                RZ_SITE(c, 2);
+                const float4* __restrict__ tp = reinterpret_cast<const float4*>(tris + first + i);
+                const float4 a = tp[0], b = tp[1], cc = tp[2];
+                float t;
+                if (moller_trumbore(lo, ld, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, cc.x), t)) {
+                    if (t < tLoc) { tLoc = t; best = first + i; }
+                }
+            }
+            // pop until an entry survives the cull against the current tLoc
+            go = false;
+            while (sp > 0) {
+                --sp;
+                const uint2 e = bstk[sp * 64];
+                if (__uint_as_float(e.y) > tLoc) continue;
+                cur = (int)e.x;
+                go = true;
+                break;
+            }
+        }
+        RZ_SITE(c, 0);
     }
     tLocOut = tLoc;
     return best < 0 ? -1 : best + I->triBase;
@@ -175,6 +198,7 @@ __device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitR
     int sp = 0;
     if (K.nTlasNodes > 0) { tstk[0] = 0; sp = 1; }
     while (sp > 0) {
+        RZ_SITE(c, 4);
         --sp;
         const int nidx = tstk[sp * 64];
         const float4* __restrict__ np = reinterpret_cast<const float4*>(K.tlasNodes + nidx);
@@ -188,6 +212,7 @@ __device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitR
                 const int instIdx = K.tlasIndices[leftFirst + i];
                 const DevInstance* __restrict__ I = K.instances + instIdx;
                 if (COUNT) { c.tlas_leaf_indices += 1; c.instances += 1; }
+                RZ_SITE(c, 5);
                 const v3 lo = x34_point(I->inv, o);
                 const v3 ld = normalize(x34_dir(I->inv, d));
                 float tLoc;
