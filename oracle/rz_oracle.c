@@ -132,6 +132,10 @@ static int traverse_blas(rctx* c, v3 o, v3 d, int nodeOff, int triOff, int gTriO
         c->cnt.blas_nodes++;
         float tmin, tmax;
         if (!intersect_aabb(o, invd, node->bmin, node->bmax, &tmin, &tmax) || tmin > tHit) continue;
+        if (node->count == 0) continue;      /* empty mesh (BVH.cpp:115-118 writes a count-0 root with inverted bounds).
+                                                FS:432 would treat it as internal and push nodes 0 and 1 for ever --
+                                                the slab test ACCEPTS an inverted box -- so the reference hangs on it;
+                                                here an empty BLAS is simply never hit. */
         if (node->count > 0) {
             for (int i = 0; i < node->count; ++i) {
                 int triIdx = gTriOff + sc->blas_indices[triOff + node->leftFirst + i];
@@ -483,8 +487,10 @@ static void* worker(void* arg) {
 int rzo_render(const rzo_scene* scene, const rzo_frame* frame, float* accum, float* ior_state,
                int x0, int y0, int x1, int y1, int nthreads, rzo_counters* counters) {
     if (!scene || !frame || !accum) return -1;
-    if (x0 < 0) x0 = 0; if (y0 < 0) y0 = 0;
-    if (x1 > frame->width) x1 = frame->width; if (y1 > frame->height) y1 = frame->height;
+    if (x0 < 0) x0 = 0;
+    if (y0 < 0) y0 = 0;
+    if (x1 > frame->width) x1 = frame->width;
+    if (y1 > frame->height) y1 = frame->height;
     if (nthreads <= 0) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
     volatile int next_row = y0;

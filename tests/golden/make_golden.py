@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures from the CPU oracle.
+
+    python tests/golden/make_golden.py
+
+The reference cannot produce them (its renderer needs an OpenGL context, its host code needs GLM; neither
+exists here -- DESIGN.md "Oracle"), and it ships no golden vectors of its own.  These files therefore pin the
+ORACLE: any drift of its output across compilers, machines or edits shows up as a diff against them, on the
+CPU suite here and (through the HIP path) on the GPU box.  Inputs are fully synthetic (rayzen_amd/scene.py).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CASES = {
+    # BASELINE.json configs[0]: Cornell-box (2 quads + 1 cube), 256x256, 4 spp, 1 bounce
+    "c1_cornell_256x256_4spp_1b": dict(scene="cornell", W=256, H=256, spp=4, bounces=1),
+    # a small all-materials frame: matte blob, glass blob, mirror cube, rough floor; 5 bounces reach Russian roulette
+    "bunny24_extras_96x54_3spp_5b": dict(scene="bunny24x", W=96, H=54, spp=3, bounces=5),
+}
+
+
+def make_scene(name):
+    from rayzen_amd import scene as S
+    if name == "cornell":
+        return S.cornell_scene()
+    if name == "bunny24x":
+        return S.bunny_scene(n=24, extras=True)
+    raise KeyError(name)
+
+
+def main():
+    from helpers import oracle_render
+    for key, c in CASES.items():
+        sc = make_scene(c["scene"])
+        img, cnt = oracle_render(sc, c["W"], c["H"], c["spp"], c["bounces"], want_counters=True)
+        path = os.path.join(HERE, key + ".npz")
+        np.savez_compressed(path, accum=img, counters=np.array([cnt[k] for k in sorted(cnt)], np.uint64),
+                            counter_names=np.array(sorted(cnt)))
+        print(key, img.shape, "mean", img[..., :3].mean(), os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,77 @@
+"""Multi-GPU sharding logic without GPUs: tile ownership and the one reduce (rayzen_amd/dist.py), rehearsed
+with world_size-2 gloo processes that use the CPU oracle as the per-rank renderer."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from rayzen_amd import dist as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("W,H,n", [(1920, 1080, 8), (256, 256, 2), (100, 37, 3), (8, 8, 4), (1, 1, 2)])
+def test_owner_map_partitions_the_frame(W, H, n):
+    own = D.owner_map(W, H, n)
+    assert own.shape == (H, W) and own.min() >= 0 and own.max() < n
+    tx, ty = D.tile_grid(W, H)
+    for y in range(0, H, 8):                      # constant inside a tile, round-robin across tiles
+        for x in range(0, W, 8):
+            t = (y // 8) * tx + x // 8
+            assert (own[y:y + 8, x:x + 8] == t % n).all()
+    assert sum(D.local_tile_count(W, H, r, n) for r in range(n)) == tx * ty
+    assert sum(D.owned_samples(W, H, 3, r, n) for r in range(n)) == W * H * 3
+
+
+def test_1080p_split_is_balanced_over_8_ranks():
+    own = D.owner_map(1920, 1080, 8)
+    counts = np.bincount(own.ravel(), minlength=8)
+    assert counts.max() - counts.min() <= 64 * 2           # within two tiles of each other
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, W, H, spp, bounces, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from oracle import rzo
+    from rayzen_amd import scene as S
+    from helpers import oracle_frame, oracle_scene
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = S.cornell_scene()
+    osc, fr = oracle_scene(sc), oracle_frame(sc, W, H, spp, bounces)
+    own = D.owner_map(W, H, world)
+    acc = np.zeros((H, W, 4), np.float32)                   # zero outside this rank's tiles
+    tx, ty = D.tile_grid(W, H)
+    for t in range(rank, tx * ty, world):                   # the same tile deal the kernel uses
+        x0, y0 = (t % tx) * 8, (t // tx) * 8
+        rzo.render(osc, fr, accum=acc, crop=(x0, y0, min(x0 + 8, W), min(y0 + 8, H)), nthreads=1)
+    assert (acc[own != rank] == 0).all()
+    ten = torch.from_numpy(acc)
+    D.reduce_accum(ten, dst=0)
+    if rank == 0:
+        np.save(out_path, ten.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_sharded_render_plus_reduce_is_bit_identical_to_single_rank(tmp_path):
+    import torch.multiprocessing as mp
+    from helpers import oracle_render
+    from rayzen_amd import scene as S
+    W, H, spp, bounces = 72, 40, 2, 3
+    out = str(tmp_path / "sum.npy")
+    mp.spawn(_worker, args=(2, _free_port(), W, H, spp, bounces, out), nprocs=2, join=True)
+    got = np.load(out)
+    want = oracle_render(S.cornell_scene(), W, H, spp, bounces, nthreads=2)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()

@@ -1,0 +1,48 @@
+"""Golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from the oracle).
+
+CPU: the oracle built here, today, still reproduces them bit for bit (pins it across compilers/machines).
+GPU: the HIP path reproduces them too (on the GPU box /root/reference and this container do not exist;
+the fixtures and the oracle source travel with the repository)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import hip_render, linf, mismatch_report, oracle_render
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(key):
+    z = np.load(os.path.join(HERE, "golden", key + ".npz"))
+    return z["accum"], dict(zip([str(n) for n in z["counter_names"]], [int(v) for v in z["counters"]]))
+
+
+def _cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("key", ["c1_cornell_256x256_4spp_1b", "bunny24_extras_96x54_3spp_5b"])
+def test_oracle_reproduces_golden(key):
+    mg = _cases()
+    c = mg.CASES[key]
+    want, wcnt = _load(key)
+    got, cnt = oracle_render(mg.make_scene(c["scene"]), c["W"], c["H"], c["spp"], c["bounces"], want_counters=True)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all(), mismatch_report(got, want)
+    assert cnt == wcnt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", ["c1_cornell_256x256_4spp_1b", "bunny24_extras_96x54_3spp_5b"])
+def test_hip_reproduces_golden(key):
+    mg = _cases()
+    c = mg.CASES[key]
+    want, wcnt = _load(key)
+    got, cnt = hip_render(mg.make_scene(c["scene"]), c["W"], c["H"], c["spp"], c["bounces"], counted=True)
+    assert linf(got, want) < 1e-4, mismatch_report(got, want)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all(), mismatch_report(got, want)
+    assert cnt == wcnt

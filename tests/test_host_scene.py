@@ -1,0 +1,120 @@
+"""Host-side scene flatten (initializeSSBOs, main.cpp:941-1035), dynamic update (main.cpp:1138-1194) and the
+OBJ reader (Mesh.cpp:6-50), against the oracle's literal restatements."""
+import os
+
+import numpy as np
+
+from oracle import rzo
+from rayzen_amd import scene as S
+
+
+def test_obj_loader_quirks(tmp_path):
+    """'v '/'f ' lines only, tokens cut at the first '/', 1-based, fan triangulation, everything else ignored."""
+    p = tmp_path / "m.obj"
+    p.write_text("# comment\no thing\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 2 0\nvn 0 0 1\nvt 0 0\n"
+                 "s off\nusemtl x\nf 1 2 3\nf 1/5/2 2/1/1 3//7 4/2 5\nf 1 2\n")
+    a = S.load_obj(str(p), 7)
+    b = rzo.load_obj(str(p), 7)
+    assert len(a) == 1 + 3 and a.tobytes() == b.tobytes()         # triangle + pentagon fan (3); 2-vertex face dropped
+    assert (a["materialIndex"] == 7).all()
+    assert a["v0"][1].tolist() == [0, 0, 0] and a["v1"][3].tolist() == [0, 1, 0] and a["v2"][3].tolist() == [0.5, 2, 0]
+
+
+def test_obj_missing_file():
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        S.load_obj("/nonexistent/thing.obj", 0)
+
+
+def _flatten_with_oracle(meshes, objects):
+    """main.cpp:941-1035 restated with the oracle's builders: per object BLAS, offsets, world AABBs, TLAS."""
+    tris, nodes, idx, inst, roots = [], [], [], [], []
+    node_off = tri_off = tri_base = 0
+    for i, (mid, m) in enumerate(objects):
+        n, ix = rzo.build_blas(meshes[mid])
+        tris.append(meshes[mid]); nodes.append(n); idx.append(ix)
+        mn, mx = rzo.world_bounds(n[0], m)
+        r = np.zeros(1, rzo.NODE)
+        r[0] = n[0]
+        r["bmin"], r["bmax"] = mn, mx
+        roots.append(r)
+        rec = np.zeros(1, rzo.INSTANCE)
+        rec["blasNodeOffset"], rec["blasTriOffset"], rec["meshIndex"], rec["globalTriOffset"] = node_off, tri_off, i, tri_base
+        rec["transform"] = m
+        inst.append(rec)
+        node_off += len(n); tri_off += len(ix); tri_base += len(meshes[mid])
+    tn, ti = rzo.build_tlas(np.concatenate(roots))
+    return np.concatenate(tris), np.concatenate(nodes), np.concatenate(idx), np.concatenate(inst), tn, ti
+
+
+def test_flatten_matches_literal_restatement():
+    meshes = [S.make_cube(0), S.make_blob(5, 2.0, 1), S.make_quad((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1), 4)]
+    objs = [(0, S.translate(S.scale(S.identity(), (8, .5, 8)), (0, -3, 0))), (1, S.translate(S.identity(), (-4, 0, 0))),
+            (1, S.translate(S.identity(), (4, 0, 0))), (2, S.identity()), (0, S.rotate(S.identity(), 0.4, (0, 1, 0)))]
+    sc = S.Scene()
+    ids = [sc.add_mesh(m) for m in meshes]
+    for mid, m in objs:
+        sc.add_object(ids[mid], m)
+    sc.build()
+    tris, nodes, idx, inst, tn, ti = _flatten_with_oracle(meshes, objs)
+    a = sc.arrays
+    assert a[S.BIND_TRIANGLES].tobytes() == tris.tobytes()
+    assert a[S.BIND_BLAS_NODES].tobytes() == nodes.tobytes()
+    assert a[S.BIND_BLAS_INDICES].tobytes() == idx.tobytes()
+    assert a[S.BIND_TLAS_NODES].tobytes() == tn.tobytes() and a[S.BIND_TLAS_INDICES].tobytes() == ti.tobytes()
+    got = a[S.BIND_INSTANCES]
+    for f in ("blasNodeOffset", "blasTriOffset", "meshIndex", "globalTriOffset", "transform"):
+        assert (got[f] == inst[f]).all(), f
+    for i, (_, m) in enumerate(objs):      # inverseTransform really is the inverse
+        M, Mi = m.reshape(4, 4).T.astype(np.float64), got["inverseTransform"][i].reshape(4, 4).T.astype(np.float64)
+        assert np.allclose(M @ Mi, np.eye(4), atol=1e-5)
+
+
+def test_share_meshes_points_instances_at_one_copy():
+    sc = S.Scene()
+    cube, blob = sc.add_mesh(S.make_cube(0)), sc.add_mesh(S.make_blob(4, 2.0, 1))
+    for k in range(3):
+        sc.add_object(blob, S.translate(S.identity(), (3.0 * k, 0, 0)))
+    sc.add_object(cube)
+    sc.build(share_meshes=True)
+    inst = sc.arrays[S.BIND_INSTANCES]
+    assert len(set(inst["blasNodeOffset"][:3])) == 1 and len(set(inst["globalTriOffset"][:3])) == 1
+    assert len(sc.arrays[S.BIND_TRIANGLES]) == 12 * 16 + 12
+    dup = S.Scene()
+    c2, b2 = dup.add_mesh(S.make_cube(0)), dup.add_mesh(S.make_blob(4, 2.0, 1))
+    for k in range(3):
+        dup.add_object(b2, S.translate(S.identity(), (3.0 * k, 0, 0)))
+    dup.add_object(c2)
+    dup.build(share_meshes=False)
+    assert len(dup.arrays[S.BIND_TRIANGLES]) == 3 * 12 * 16 + 12        # the reference duplicates per object
+
+
+def test_update_dynamic_rebuilds_only_instances_and_tlas():
+    sc = S.instanced_scene(n=4, count=4)
+    before = {b: sc.arrays[b].copy() for b in sc.arrays}
+    for oid, t in zip(sc.instance_ids, S.instanced_transforms(7, 4)):
+        sc.set_transform(oid, t)
+    sc.update_dynamic()
+    for b in (S.BIND_TRIANGLES, S.BIND_BLAS_NODES, S.BIND_BLAS_INDICES):
+        assert sc.arrays[b].tobytes() == before[b].tobytes()
+    assert sc.arrays[S.BIND_INSTANCES].tobytes() != before[S.BIND_INSTANCES].tobytes()
+    assert len(sc.arrays[S.BIND_TLAS_NODES]) == len(before[S.BIND_TLAS_NODES])      # 2*I-1, fixed
+    # equals a from-scratch build with the new transforms
+    fresh = S.Scene()
+    floor, bunny = fresh.add_mesh(S.make_cube(4)), fresh.add_mesh(S.make_blob(4, 2.8, 0))
+    fresh.add_object(floor, S.translate(S.scale(S.identity(), (8.0, 0.5, 8.0)), (0.0, -3.0, 0.0)))
+    for t in S.instanced_transforms(7, 4):
+        fresh.add_object(bunny, t)
+    fresh.build(share_meshes=True)
+    for b in (S.BIND_INSTANCES, S.BIND_TLAS_NODES, S.BIND_TLAS_INDICES):
+        assert sc.arrays[b].tobytes() == fresh.arrays[b].tobytes()
+
+
+def test_camera_matrices_are_consistent():
+    cam = S.Camera(position=(1, 2, 3), target=(0.1, -0.2, -1), fov=70.0, aspect=16 / 9)
+    V, P = cam.view.reshape(4, 4).T.astype(np.float64), cam.proj.reshape(4, 4).T.astype(np.float64)
+    assert np.allclose(V @ cam.inv_view.reshape(4, 4).T, np.eye(4), atol=1e-5)
+    assert np.allclose(P @ cam.inv_proj.reshape(4, 4).T, np.eye(4), atol=1e-4)
+    assert np.allclose((V @ np.array([1, 2, 3, 1.0]))[:3], 0, atol=1e-5)             # eye maps to the origin
+    f = 1.0 / np.tan(np.radians(70.0) / 2)
+    assert abs(P[1, 1] - f) < 1e-5 and abs(P[0, 0] - f / (16 / 9)) < 1e-5 and P[3, 2] == -1.0
