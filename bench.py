@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--spp", type=int, default=64, help="samples per pixel per GPU")
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--mesh-n", type=int, default=76, help="bunny stand-in has 12*n*n triangles")
+    ap.add_argument("--backend", choices=["auto", "pixel", "wavefront"], default="auto",
+                    help="render pipeline: auto = the library's default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (default: min(16, usable cores) = the box's CPU share)")
     ap.add_argument("--cpu-bands", type=int, default=18, help="oracle sample: this many 8-row bands of the frame")
@@ -76,7 +78,7 @@ def main():
     W, H, bounces = a.width, a.height, a.bounces
     spp_total = a.spp * world          # every rank renders ALL samples of its own pixels
     sc = S.bunny_scene(n=a.mesh_n, aspect=W / H)
-    r = Renderer(local_rank)
+    r = Renderer(local_rank, {"auto": 0, "pixel": 1, "wavefront": 2}[a.backend])
     r.upload_scene(sc)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)    # zero outside this rank's tiles
     stream = torch.cuda.Stream(dev)     # the kernels, the reduce and the fences all order on this stream

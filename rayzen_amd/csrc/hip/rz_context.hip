@@ -22,9 +22,14 @@
 
 #include "rayzen_hip.h"
 #include "rz_scene_dev.h"
+#include "rz_wavefront.h"
 
 namespace rz {
+#ifdef RZ_PROF
+void dump_wave_log(int nWaves);
+#endif
 void launch_render_pixels(const KParams& K, bool counted, hipStream_t stream);
+void launch_render_samples(const KParams& K, bool counted, bool first, bool countPixels, hipStream_t stream);
 void launch_resolve(const float4* accum, uchar4* out, int n, hipStream_t stream);
 }  // namespace rz
 
@@ -99,6 +104,13 @@ struct rz_ctx {
     bool haveFrame = false;
     rz_frame_params frame{};
     DevBuf ownAccum, dIor;
+    // queued pipeline (rz_wavefront.hip)
+    DevBuf wfState, wfQueues, wfCounts, dContrib;
+    bool sceneHasTransparency = true;   // some triangle uses a material with transparency > 0
+    int wfSlots = 0;
+    int wfTraceBlocks = 0;
+    int* wfHostCount = nullptr;     // pinned
+    long long lastRounds = 0;
     void* extAccum = nullptr;
     size_t extAccumBytes = 0;
 };
@@ -331,15 +343,117 @@ int finalize(rz_ctx* c) {
         if (rc != RZ_OK) return rc;
     }
     // material indices are data the kernels index with: check them once
-    if (c->geomDirty || c->matDirty) {
+    if (c->geomDirty || c->matDirty || c->instDirty) {
         const int nMat = (int)hostCount<rz_material>(c, RZ_BIND_MATERIALS);
-        for (const DevTri& t : c->hTris)
+        const rz_material* mats = hostArr<rz_material>(c, RZ_BIND_MATERIALS);
+        bool transparent = false;
+        for (const DevTri& t : c->hTris) {
             if (t.mat < 0 || t.mat >= nMat)
                 return fail(c, RZ_ERR_BAD_SCENE, "triangle %d has materialIndex %d, %d materials uploaded", t.src, t.mat, nMat);
+            transparent = transparent || (mats[t.mat].transparency > 0.0f) || !(mats[t.mat].transparency == mats[t.mat].transparency);
+        }
+        c->sceneHasTransparency = transparent;
     }
     // uploads read the caller-visible host copies: let them land before rz_update may patch those
     RZ_HIP(c, hipStreamSynchronize(c->stream));
     c->geomDirty = c->instDirty = c->tlasDirty = c->matDirty = c->lightDirty = false;
+    return RZ_OK;
+}
+
+constexpr int kWfMaxRounds = 16384;
+
+bool use_wavefront(const rz_ctx* c, const KParams& K) {
+    if (c->flags & RZ_FLAG_MEGAKERNEL) return false;
+    if (K.maxBounces > 4095 || K.nLights > 4095) return false;   // state packing of rz_wavefront.hip
+    return (c->flags & RZ_FLAG_WAVEFRONT) != 0;
+}
+
+// Queued pipeline: wf_init, then rounds of (wf_trace, wf_shade) until the queue is empty.  The queue length
+// lives on the device; rounds are enqueued blind in batches and the count is read back once per batch.
+int render_wavefront(rz_ctx* c, const KParams& K, bool counted) {
+    const int nSlots = K.nLocalTiles * 64;
+    if (nSlots <= 0) { c->lastLaunches = 0; return RZ_OK; }
+    int rc = ensure(c, c->wfState, (size_t)nSlots * 16 * 9);
+    if (rc != RZ_OK) return rc;
+    rc = ensure(c, c->wfQueues, (size_t)nSlots * 4 * 2);
+    if (rc != RZ_OK) return rc;
+    rc = ensure(c, c->wfCounts, (size_t)kWfMaxRounds * 4 * 2);
+    if (rc != RZ_OK) return rc;
+    if (!c->wfHostCount) RZ_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->wfHostCount), 64, hipHostMallocDefault));
+    WFParams Q{};
+    float4* st = static_cast<float4*>(c->wfState.p);
+    Q.rayO = st; Q.rayD = st + (size_t)nSlots; Q.hit = st + (size_t)nSlots * 2;
+    Q.s0 = st + (size_t)nSlots * 3; Q.s1 = st + (size_t)nSlots * 4; Q.s2 = st + (size_t)nSlots * 5;
+    Q.s3 = st + (size_t)nSlots * 6; Q.s4 = st + (size_t)nSlots * 7; Q.s5 = st + (size_t)nSlots * 8;
+    Q.queue[0] = static_cast<int*>(c->wfQueues.p);
+    Q.queue[1] = Q.queue[0] + nSlots;
+    Q.counts = static_cast<int*>(c->wfCounts.p);
+    Q.cursors = Q.counts + kWfMaxRounds;
+    Q.nSlots = nSlots;
+    Q.maxRounds = kWfMaxRounds - 1;
+    const size_t lds = wf_trace_lds_bytes(K);
+    if (wf_set_lds_limit(lds) != 0) return fail(c, RZ_ERR_HIP, "cannot reserve %zu B of LDS for the trace kernel", lds);
+    if (c->wfTraceBlocks <= 0) {
+        hipDeviceProp_t prop;
+        RZ_HIP(c, hipGetDeviceProperties(&prop, c->device));
+        const int perCU = std::max(1, std::min(8, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
+        c->wfTraceBlocks = prop.multiProcessorCount * perCU;
+    }
+    const int traceBlocks = std::max(1, std::min(c->wfTraceBlocks, (nSlots + 255) / 256));
+    const int shadeBlocks = std::max(1, std::min(2048, (nSlots + 1023) / 1024));
+    RZ_HIP(c, hipMemsetAsync(c->wfCounts.p, 0, (size_t)kWfMaxRounds * 4 * 2, c->stream));
+    launch_wf_init(K, Q, counted, c->stream);
+    int round = 0;
+    int launches = 1;
+    long long rounds = 0;
+    int batch = std::max(1, std::min(K.spp, 1024));     // every pixel needs at least spp closest-hit queries
+    for (;;) {
+        for (int k = 0; k < batch; ++k, ++round) launch_wf_round(K, Q, round, traceBlocks, shadeBlocks, counted, c->stream);
+        launches += 2 * batch;
+        rounds += batch;
+        RZ_HIP(c, hipGetLastError());
+        RZ_HIP(c, hipMemcpyAsync(c->wfHostCount, Q.counts + round, 4, hipMemcpyDeviceToHost, c->stream));
+        RZ_HIP(c, hipStreamSynchronize(c->stream));
+        const int alive = *c->wfHostCount;
+        if (alive <= 0) break;
+        batch = 16;
+        if (round + batch + 1 >= kWfMaxRounds) {         // recycle the counter arrays, keeping queue parity
+            RZ_HIP(c, hipMemsetAsync(c->wfCounts.p, 0, (size_t)kWfMaxRounds * 4 * 2, c->stream));
+            const int r0 = round & 1;
+            RZ_HIP(c, hipMemcpyAsync(Q.counts + r0, c->wfHostCount, 4, hipMemcpyHostToDevice, c->stream));
+            round = r0;
+        }
+    }
+    c->lastLaunches = launches;
+    c->lastRounds = rounds;
+    return RZ_OK;
+}
+
+// One lane per sample is exact only while FS:674's currentIor cannot change, i.e. no triangle is transparent.
+bool use_samples(const rz_ctx* c) {
+    if (c->flags & RZ_FLAG_MEGAKERNEL) return false;
+    return !c->sceneHasTransparency;
+}
+
+int render_samples(rz_ctx* c, KParams K, bool counted) {
+    K.nSlots = K.nLocalTiles * 64;
+    if (K.nSlots <= 0) { c->lastLaunches = 0; return RZ_OK; }
+    // the contribution buffer holds `chunk` samples per owned pixel; bound it to ~6 GiB
+    const size_t perSample = (size_t)K.nSlots * 32;
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)K.spp, ((size_t)6 << 30) / perSample));
+    if (chunk >= 64) chunk = chunk / 64 * 64;       // whole waves per pixel
+    int rc = ensure(c, c->dContrib, perSample * (size_t)chunk);
+    if (rc != RZ_OK) return rc;
+    K.contrib = static_cast<float4*>(c->dContrib.p);
+    const int base0 = K.sampleBase, total = K.spp;
+    int launches = 0;
+    for (int done = 0; done < total; done += chunk) {
+        K.chunkSpp = std::min(chunk, total - done);
+        K.sampleBase = base0 + done;
+        launch_render_samples(K, counted, base0 == 0 && done == 0, counted && done == 0, c->stream);
+        launches += 2;
+    }
+    c->lastLaunches = launches;
     return RZ_OK;
 }
 
@@ -385,7 +499,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     std::memcpy(K.invProj, f.inv_proj, 64);
     std::memcpy(K.camPos, f.cam_pos, 12);
     const size_t perWave = (size_t)K.blasStackCap * 512 + (size_t)K.tlasStackCap * 256;
-    if (perWave * 4 > 160 * 1024)
+    if (perWave * 4 > 160 * 1024)   // sized for the largest (4-wave) workgroup
         return fail(c, RZ_ERR_BAD_SCENE, "BLAS depth %d needs %zu B of LDS stack per wave; the limit is %d", c->maxBlasDepth, perWave, 40 * 1024);
     if (counted) {
         rc = ensure(c, c->dCounters, sizeof(DevCounters) + 32 * sizeof(unsigned long long));
@@ -395,13 +509,21 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     }
     const int slot = c->ringHead;
     RZ_HIP(c, hipEventRecord(c->evStart[slot], c->stream));
-    launch_render_pixels(K, counted, c->stream);
+    if (use_wavefront(c, K)) {
+        rc = render_wavefront(c, K, counted);
+        if (rc != RZ_OK) return rc;
+    } else if (use_samples(c)) {
+        rc = render_samples(c, K, counted);
+        if (rc != RZ_OK) return rc;
+    } else {
+        launch_render_pixels(K, counted, c->stream);
+        c->lastLaunches = 1;
+    }
     RZ_HIP(c, hipGetLastError());
     RZ_HIP(c, hipEventRecord(c->evStop[slot], c->stream));
     c->ringHead = (slot + 1) % rz_ctx::kRing;
     c->ringCount = std::min(c->ringCount + 1, (int)rz_ctx::kRing);
     c->timed = true;
-    c->lastLaunches = 1;
     if (counted && out) {
         DevCounters h{};
         RZ_HIP(c, hipMemcpyAsync(&h, c->dCounters.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -413,10 +535,15 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
 #ifdef RZ_PROF
         unsigned long long pr[32];
         RZ_HIP(c, hipMemcpy(pr, static_cast<char*>(c->dCounters.p) + sizeof(DevCounters), sizeof pr, hipMemcpyDeviceToHost));
-        static const char* names[] = {"blas loop iter", "leaf branch", "triangle test", "internal branch", "tlas pop", "instance enter", "outer iter", "begin_sample"};
+        const bool wf = (c->flags & RZ_FLAG_WAVEFRONT) != 0;
+        if (!wf) dump_wave_log(K.nLocalTiles);
+        static const char* namesPx[] = {"blas loop iter", "leaf branch", "triangle test", "internal branch", "tlas pop", "instance enter", "outer iter", "begin_sample"};
+        static const char* namesWf[] = {"outer iter", "refill lane", "tlas step", "descend step", "leaf phase", "triangle test", "instance done", "-"};
+        const char** names = wf ? namesWf : namesPx;
         for (int k = 0; k < 8; ++k)
             fprintf(stderr, "[rz_prof] %-16s wave-execs %12llu  lanes %14llu  avg active lanes %.1f\n", names[k], pr[2 * k], pr[2 * k + 1], pr[2 * k] ? (double)pr[2 * k + 1] / (double)pr[2 * k] : 0.0);
-        fprintf(stderr, "[rz_prof] wave cycles: begin %llu  trace %llu  advance %llu\n", pr[16], pr[17], pr[18]);
+        if (wf) fprintf(stderr, "[rz_prof] wave cycles: refill %llu  tlas %llu  descend %llu  leaf %llu  finish+store %llu\n", pr[16], pr[17], pr[18], pr[19], pr[20]);
+        else fprintf(stderr, "[rz_prof] wave cycles: begin %llu  trace %llu  advance %llu\n", pr[16], pr[17], pr[18]);
 #endif
     }
     return RZ_OK;
@@ -470,8 +597,9 @@ void rz_destroy(rz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
-                      &c->dCounters, &c->dResolve, &c->ownAccum, &c->dIor})
+                      &c->dCounters, &c->dResolve, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts, &c->dContrib})
         b->release();
+    if (c->wfHostCount) (void)hipHostFree(c->wfHostCount);
     for (int i = 0; i < rz_ctx::kRing; ++i) {
         if (c->evStart[i]) (void)hipEventDestroy(c->evStart[i]);
         if (c->evStop[i]) (void)hipEventDestroy(c->evStop[i]);

@@ -40,6 +40,10 @@ struct Path {
     int li;             // light index
     float vis, traveled, maxDist;
     int iter;
+    // the (at most two) terms this sample adds to the pixel's colour, in the shader's order: FS:717 then FS:709.
+    // The one-lane-per-pixel kernel adds them to `color` on the spot and never reads these; the
+    // one-lane-per-sample kernel stores them and rz_sum_samples replays the adds in order.
+    v3 addLight, addSky;
 };
 
 // FS:204-212 + FS:688-692
@@ -62,6 +66,8 @@ __device__ __forceinline__ void begin_sample(const KParams& K, Path& P, Tally& c
     P.throughput = mk3(1.0f, 1.0f, 1.0f);
     P.bounce = 0;
     P.mode = MODE_SEGMENT;
+    P.addLight = mk3(0.0f, 0.0f, 0.0f);
+    P.addSky = mk3(0.0f, 0.0f, 0.0f);
 }
 
 __device__ __forceinline__ void end_sample(Path& P) {
@@ -237,7 +243,8 @@ __device__ __forceinline__ void scatter(const KParams& K, Path& P) {
 
 // Lighting of the parked point is complete (or there are no lights): FS:717, then scatter.
 __device__ __forceinline__ void finish_lighting(const KParams& K, Path& P) {
-    P.color = P.color + P.throughput * P.lacc;
+    P.addLight = P.throughput * P.lacc;
+    P.color = P.color + P.addLight;
     scatter(K, P);
 }
 
@@ -248,7 +255,8 @@ __device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, c
         if (!found) {   // FS:705-711
             const float t = 0.5f * (normalize(P.d).y + 1.0f);
             const v3 sky = mk3(mix_(0.15f, 0.5f, t), mix_(0.25f, 0.7f, t), mix_(0.45f, 1.0f, t));
-            P.color = P.color + P.throughput * sky;
+            P.addSky = P.throughput * sky;
+            P.color = P.color + P.addSky;
             end_sample(P);
             return;
         }

@@ -23,10 +23,15 @@ def oracle_render(scene, width, height, spp, bounces, crop=None, nthreads=8, wan
     return rzo.render(osc, fr, crop=crop, nthreads=nthreads, want_counters=want_counters)
 
 
+BACKENDS = {"auto": 0, "pixel": 1, "wavefront": 2}      # RZ_FLAG_MEGAKERNEL / RZ_FLAG_WAVEFRONT of include/rayzen_hip.h
+
+
 def hip_render(scene, width, height, spp, bounces, counted=False, chunk=None, tile_rank=0, tile_nranks=1,
-               num_lights=None, renderer=None):
+               num_lights=None, renderer=None, backend=None):
+    import os
     from rayzen_amd.renderer import Renderer, frame_params
-    r = renderer or Renderer(0)
+    backend = backend or os.environ.get("RZ_TEST_BACKEND")
+    r = renderer or Renderer(0, BACKENDS[backend] if backend else 0)
     r.upload_scene(scene)
     nl = len(scene.lights) if num_lights is None else num_lights
     counters = None
