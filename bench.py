@@ -148,7 +148,7 @@ def main():
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                           "kernel": "rz_render_pixels", "kernel_ms": round(kms, 3),
+                           "kernel": r.last_kernel_name(), "kernel_ms": round(kms, 3),
                            "algorithmic_bytes_per_launch": int(alg_bytes),
                            "algorithmic_bytes_per_sample": round(alg_bytes / max(counters["samples"], 1), 1),
                            "kernel_msamples_per_s": round(counters["samples"] / (kms * 1e-3) / 1e6, 2)}

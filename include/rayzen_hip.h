@@ -213,6 +213,10 @@ int rz_last_render_ms(rz_ctx* ctx, float* ms, int* launches);
  * at most 64 -- and returns how many; negative on error.  Synchronises on those events only, so a
  * timed loop can issue its launches back to back and collect their GPU times afterwards. */
 int rz_render_history_ms(rz_ctx* ctx, float* ms, int cap);
+/* Name of the render kernel the last rz_render used (the one those event pairs bracket): the library picks
+ * "rz_render_samples" (one lane per sample; scenes in which no triangle uses a transparent material) or
+ * "rz_render_pixels" (one lane per pixel; any scene), or the queued pipeline if RZ_FLAG_WAVEFRONT was given. */
+const char* rz_last_kernel_name(const rz_ctx* ctx);
 
 /* Device pointer of the accumulation buffer currently in use. */
 void* rz_accum_device_ptr(rz_ctx* ctx);

@@ -14,7 +14,7 @@ HOST_SO = os.path.join(_HERE, "lib", "librayzen_host.so")
 HIP_SYMBOLS = (
     "rz_create", "rz_destroy", "rz_last_error", "rz_upload", "rz_update", "rz_set_frame", "rz_set_stream",
     "rz_bind_accum", "rz_render", "rz_render_counted", "rz_sync", "rz_clear_accum", "rz_read_accum",
-    "rz_resolve_rgba8", "rz_last_render_ms", "rz_render_history_ms", "rz_accum_device_ptr", "rz_version", "rz_sizeof",
+    "rz_resolve_rgba8", "rz_last_render_ms", "rz_render_history_ms", "rz_last_kernel_name", "rz_accum_device_ptr", "rz_version", "rz_sizeof",
 )
 # the symbols include/rayzen_host.h declares
 HOST_SYMBOLS = (
@@ -75,6 +75,7 @@ def hip():
         L.rz_resolve_rgba8.restype, L.rz_resolve_rgba8.argtypes = i, [vp, vp, sz]
         L.rz_last_render_ms.restype, L.rz_last_render_ms.argtypes = i, [vp, C.POINTER(C.c_float), C.POINTER(i)]
         L.rz_render_history_ms.restype, L.rz_render_history_ms.argtypes = i, [vp, C.POINTER(C.c_float), i]
+        L.rz_last_kernel_name.restype, L.rz_last_kernel_name.argtypes = C.c_char_p, [vp]
         L.rz_accum_device_ptr.restype, L.rz_accum_device_ptr.argtypes = vp, [vp]
         L.rz_version.restype, L.rz_version.argtypes = C.c_char_p, []
         L.rz_sizeof.restype, L.rz_sizeof.argtypes = sz, [i]

@@ -29,7 +29,8 @@ namespace rz {
 void dump_wave_log(int nWaves);
 #endif
 void launch_render_pixels(const KParams& K, bool counted, hipStream_t stream);
-void launch_render_samples(const KParams& K, bool counted, bool first, bool countPixels, hipStream_t stream);
+void launch_render_samples(const KParams& K, bool counted, hipStream_t stream);
+void launch_sum_samples(const KParams& K, bool first, bool countPixels, hipStream_t stream);
 void launch_resolve(const float4* accum, uchar4* out, int n, hipStream_t stream);
 }  // namespace rz
 
@@ -111,6 +112,7 @@ struct rz_ctx {
     int wfTraceBlocks = 0;
     int* wfHostCount = nullptr;     // pinned
     long long lastRounds = 0;
+    const char* lastKernel = "";
     void* extAccum = nullptr;
     size_t extAccumBytes = 0;
 };
@@ -435,9 +437,14 @@ bool use_samples(const rz_ctx* c) {
     return !c->sceneHasTransparency;
 }
 
-int render_samples(rz_ctx* c, KParams K, bool counted) {
+int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     K.nSlots = K.nLocalTiles * 64;
-    if (K.nSlots <= 0) { c->lastLaunches = 0; return RZ_OK; }
+    if (K.nSlots <= 0) {
+        RZ_HIP(c, hipEventRecord(c->evStart[evSlot], c->stream));
+        RZ_HIP(c, hipEventRecord(c->evStop[evSlot], c->stream));
+        c->lastLaunches = 0;
+        return RZ_OK;
+    }
     // the contribution buffer holds `chunk` samples per owned pixel; bound it to ~6 GiB
     const size_t perSample = (size_t)K.nSlots * 32;
     int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)K.spp, ((size_t)6 << 30) / perSample));
@@ -447,10 +454,13 @@ int render_samples(rz_ctx* c, KParams K, bool counted) {
     K.contrib = static_cast<float4*>(c->dContrib.p);
     const int base0 = K.sampleBase, total = K.spp;
     int launches = 0;
+    RZ_HIP(c, hipEventRecord(c->evStart[evSlot], c->stream));
     for (int done = 0; done < total; done += chunk) {
         K.chunkSpp = std::min(chunk, total - done);
         K.sampleBase = base0 + done;
-        launch_render_samples(K, counted, base0 == 0 && done == 0, counted && done == 0, c->stream);
+        launch_render_samples(K, counted, c->stream);
+        if (done + chunk >= total) RZ_HIP(c, hipEventRecord(c->evStop[evSlot], c->stream));
+        launch_sum_samples(K, base0 == 0 && done == 0, counted && done == 0, c->stream);
         launches += 2;
     }
     c->lastLaunches = launches;
@@ -507,20 +517,27 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
         RZ_HIP(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(DevCounters) + 32 * sizeof(unsigned long long), c->stream));
         K.counters = static_cast<DevCounters*>(c->dCounters.p);
     }
+    // The event pair brackets the render kernels of this call (for the one-lane-per-sample path: the
+    // rz_render_samples launches; its small ordered-sum kernel runs after the stop event when unchunked).
     const int slot = c->ringHead;
-    RZ_HIP(c, hipEventRecord(c->evStart[slot], c->stream));
     if (use_wavefront(c, K)) {
+        RZ_HIP(c, hipEventRecord(c->evStart[slot], c->stream));
         rc = render_wavefront(c, K, counted);
         if (rc != RZ_OK) return rc;
+        RZ_HIP(c, hipEventRecord(c->evStop[slot], c->stream));
+        c->lastKernel = "wf_trace+wf_shade";
     } else if (use_samples(c)) {
-        rc = render_samples(c, K, counted);
+        rc = render_samples(c, K, counted, slot);
         if (rc != RZ_OK) return rc;
+        c->lastKernel = "rz_render_samples";
     } else {
+        RZ_HIP(c, hipEventRecord(c->evStart[slot], c->stream));
         launch_render_pixels(K, counted, c->stream);
+        RZ_HIP(c, hipEventRecord(c->evStop[slot], c->stream));
         c->lastLaunches = 1;
+        c->lastKernel = "rz_render_pixels";
     }
     RZ_HIP(c, hipGetLastError());
-    RZ_HIP(c, hipEventRecord(c->evStop[slot], c->stream));
     c->ringHead = (slot + 1) % rz_ctx::kRing;
     c->ringCount = std::min(c->ringCount + 1, (int)rz_ctx::kRing);
     c->timed = true;
@@ -752,6 +769,8 @@ int rz_last_render_ms(rz_ctx* c, float* ms, int* launches) {
     if (launches) *launches = c->lastLaunches;
     return RZ_OK;
 }
+
+const char* rz_last_kernel_name(const rz_ctx* c) { return c ? c->lastKernel : ""; }
 
 int rz_render_history_ms(rz_ctx* c, float* ms, int cap) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");

@@ -21,7 +21,7 @@
 namespace rz {
 
 #ifndef RZ_WAVES_PER_BLOCK
-#define RZ_WAVES_PER_BLOCK 4
+#define RZ_WAVES_PER_BLOCK 1   // measured on C2: 4 -> 98.9 ms, 2 -> 88.5 ms, 1 -> 88.0 ms (a 4-wave group holds its CU slots until its slowest tile ends)
 #endif
 constexpr int WAVES_PER_BLOCK = RZ_WAVES_PER_BLOCK;
 #ifndef RZ_MIN_WAVES_PER_SIMD
@@ -167,11 +167,29 @@ __global__ __launch_bounds__(64, RZ_MIN_WAVES_PER_SIMD) void rz_render_samples(c
             begin_sample<COUNT>(K, P, c);
         }
     }
+#ifdef RZ_PROF
+    unsigned long long tTrace = 0, tAdv = 0;
+    while (P.mode != MODE_DONE) {
+        RZ_SITE(c, 6);
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        HitRec h;
+        const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, c);
+        unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        advance<COUNT>(K, P, found, h, c);
+        tTrace += t2 - t1; tAdv += __builtin_amdgcn_s_memtime() - t2;
+    }
+    if (COUNT) {
+        unsigned long long* pr = reinterpret_cast<unsigned long long*>(K.counters + 1);
+        for (int k = 0; k < 16; ++k) if (c.p[k]) atomicAdd(&pr[k], (unsigned long long)c.p[k]);
+        if (lane == 0) { atomicAdd(&pr[17], tTrace); atomicAdd(&pr[18], tAdv); }
+    }
+#else
     while (P.mode != MODE_DONE) {
         HitRec h;
         const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, c);
         advance<COUNT>(K, P, found, h, c);
     }
+#endif
     if (active) {
         K.contrib[2 * item] = make_float4(P.addLight.x, P.addLight.y, P.addLight.z, 0.0f);
         K.contrib[2 * item + 1] = make_float4(P.addSky.x, P.addSky.y, P.addSky.z, 0.0f);
@@ -265,7 +283,7 @@ void dump_wave_log(int nWaves) {
 }
 #endif
 
-void launch_render_samples(const KParams& K, bool counted, bool first, bool countPixels, hipStream_t stream) {
+void launch_render_samples(const KParams& K, bool counted, hipStream_t stream) {
     const long long nItems = (long long)K.nSlots * K.chunkSpp;
     const long long blocks = (nItems + 63) / 64;
     if (blocks <= 0) return;
@@ -274,6 +292,10 @@ void launch_render_samples(const KParams& K, bool counted, bool first, bool coun
         hipLaunchKernelGGL(rz_render_samples<true>, dim3((unsigned)blocks), dim3(64), lds, stream, K);
     else
         hipLaunchKernelGGL(rz_render_samples<false>, dim3((unsigned)blocks), dim3(64), lds, stream, K);
+}
+
+void launch_sum_samples(const KParams& K, bool first, bool countPixels, hipStream_t stream) {
+    if (K.nSlots <= 0) return;
     hipLaunchKernelGGL(rz_sum_samples, dim3((K.nSlots + 255) / 256), dim3(256), 0, stream, K, first ? 1 : 0,
                        countPixels ? 1 : 0);
 }

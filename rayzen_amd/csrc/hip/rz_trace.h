@@ -49,6 +49,10 @@ struct Tally {          // per-thread counts of the REFERENCE algorithm's memory
 #define RZ_SITE(c, k) do { } while (0)
 #endif
 
+// "These registers are needed now": stops hipcc from splitting a record load and sinking part of it into a later
+// branch (seen in the ISA: the left child's ref and each triangle's v0 were re-fetched by a dependent load).
+#define RZ_KEEP4(q) asm volatile("" : "+v"((q).x), "+v"((q).y), "+v"((q).z), "+v"((q).w))
+
 struct HitRec {
     float t;
     v3 p;       // world-space hit point
@@ -130,7 +134,8 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
         while (go && cur >= 0) {
             RZ_SITE(c, 3);
             const float4* __restrict__ pp = reinterpret_cast<const float4*>(pairs + cur);
-            const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+            float4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
+            RZ_KEEP4(p0); RZ_KEEP4(p2);
             if (COUNT) c.blas_nodes += 2;        // the shader pushes, and later pops, both children
             float tl, tr;
             const bool hl = slab(lo, inv, p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, tl);
@@ -145,7 +150,8 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
                 go = false;
                 while (sp > 0) {
                     --sp;
-                    const uint2 e = bstk[sp * 64];
+                    uint2 e = bstk[sp * 64];
+                    asm volatile("" : "+v"(e.x), "+v"(e.y));     // one ds_read_b64, not two b32 with a second wait
                     if (__uint_as_float(e.y) > tLoc) continue;
                     cur = (int)e.x;
                     go = true;
@@ -163,7 +169,8 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
             for (int i = 0; i < count; ++i) {
                 RZ_SITE(c, 2);
                 const float4* __restrict__ tp = reinterpret_cast<const float4*>(tris + first + i);
-                const float4 a = tp[0], b = tp[1], cc = tp[2];
+                float4 a = tp[0], b = tp[1], cc = tp[2];
+                RZ_KEEP4(a);
                 float t;
                 if (moller_trumbore(lo, ld, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, cc.x), t)) {
                     if (t < tLoc) { tLoc = t; best = first + i; }
@@ -173,7 +180,8 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
             go = false;
             while (sp > 0) {
                 --sp;
-                const uint2 e = bstk[sp * 64];
+                uint2 e = bstk[sp * 64];
+                asm volatile("" : "+v"(e.x), "+v"(e.y));
                 if (__uint_as_float(e.y) > tLoc) continue;
                 cur = (int)e.x;
                 go = true;

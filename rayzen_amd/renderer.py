@@ -122,6 +122,9 @@ class Renderer:
             self._check(n, "rz_render_history_ms")
         return [float(buf[k]) for k in range(n)]
 
+    def last_kernel_name(self):
+        return self._L.rz_last_kernel_name(self._c).decode()
+
     def accum_device_ptr(self):
         return self._L.rz_accum_device_ptr(self._c)
 
