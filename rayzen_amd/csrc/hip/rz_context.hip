@@ -554,7 +554,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
         RZ_HIP(c, hipMemcpy(pr, static_cast<char*>(c->dCounters.p) + sizeof(DevCounters), sizeof pr, hipMemcpyDeviceToHost));
         const bool wf = (c->flags & RZ_FLAG_WAVEFRONT) != 0;
         if (!wf) dump_wave_log(K.nLocalTiles);
-        static const char* namesPx[] = {"blas loop iter", "leaf branch", "triangle test", "internal branch", "tlas pop", "instance enter", "outer iter", "begin_sample"};
+        static const char* namesPx[] = {"blas loop iter", "leaf branch", "triangle test", "internal branch", "tlas pop", "instance enter", "outer iter", "uniform pair"};
         static const char* namesWf[] = {"outer iter", "refill lane", "tlas step", "descend step", "leaf phase", "triangle test", "instance done", "-"};
         const char** names = wf ? namesWf : namesPx;
         for (int k = 0; k < 8; ++k)

@@ -137,8 +137,11 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
 //   item = slot * chunkSpp + s (s fastest): a wave's 64 lanes are consecutive samples of one pixel (spp >= 64), so
 //   primary and shadow rays of a wave are near-identical -- uniform traversal, L1 broadcast instead of 64
 //   divergent lines -- and a heavy pixel costs ONE sample's latency instead of spp of them: no tail.
+#ifndef RZ_SAMPLES_MIN_WAVES
+#define RZ_SAMPLES_MIN_WAVES 3   // measured on C2: 2 -> 29.0 ms, 3 -> 22.1 ms, 4 -> 22.1 ms (the kernel is issue-bound; a third wave overlaps scalar/VMEM/LDS issue with VALU)
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(64, RZ_MIN_WAVES_PER_SIMD) void rz_render_samples(const KParams K) {
+__global__ __launch_bounds__(64, RZ_SAMPLES_MIN_WAVES) void rz_render_samples(const KParams K) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     uint2* bstk = reinterpret_cast<uint2*>(lds_raw) + lane;
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(64, RZ_MIN_WAVES_PER_SIMD) void rz_render_samples(c
         HitRec h;
         const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, c);
         unsigned long long t2 = __builtin_amdgcn_s_memtime();
-        advance<COUNT>(K, P, found, h, c);
+        advance<COUNT, false>(K, P, found, h, c);
         tTrace += t2 - t1; tAdv += __builtin_amdgcn_s_memtime() - t2;
     }
     if (COUNT) {
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(64, RZ_MIN_WAVES_PER_SIMD) void rz_render_samples(c
     while (P.mode != MODE_DONE) {
         HitRec h;
         const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, c);
-        advance<COUNT>(K, P, found, h, c);
+        advance<COUNT, false>(K, P, found, h, c);
     }
 #endif
     if (active) {

@@ -109,7 +109,9 @@ __device__ __forceinline__ v3 random_hemisphere_direction(v3 normal, v2 seed) {
 
 // Set up the shadow query of light P.li for the parked surface point
 // (FS:578-588 transparent branch, FS:622-635 opaque branch).
-template <bool COUNT>
+// GLASS = false: the caller guarantees that no triangle of the scene uses a transparent material, so every
+// `transparency > 0` branch of the shader is dead and is compiled out (fewer live registers, less code).
+template <bool COUNT, bool GLASS>
 __device__ __forceinline__ void start_light(const KParams& K, Path& P, Tally& c) {
     const DevLight L = K.lights[P.li];
     const DevMaterial M = K.materials[P.hmat];
@@ -118,7 +120,7 @@ __device__ __forceinline__ void start_light(const KParams& K, Path& P, Tally& c)
     if (L.posdir[3] == 1.0f) {
         const v3 lv = mk3(L.posdir[0], L.posdir[1], L.posdir[2]) - P.hp;
         const float dist = fmax_(length(lv), 0.001f);
-        dir = (M.transparency > 0.0f) ? lv / dist : normalize(lv);
+        dir = (GLASS && M.transparency > 0.0f) ? lv / dist : normalize(lv);
         P.maxDist = dist;
     } else {
         dir = normalize(mk3(L.posdir[0], L.posdir[1], L.posdir[2]));
@@ -133,6 +135,7 @@ __device__ __forceinline__ void start_light(const KParams& K, Path& P, Tally& c)
 }
 
 // The light P.li is visible with P.vis: add its term (FS:589-607 / FS:636-659).
+template <bool GLASS>
 __device__ __forceinline__ void shade_light(const KParams& K, Path& P) {
     const DevLight L = K.lights[P.li];
     const DevMaterial M = K.materials[P.hmat];
@@ -143,7 +146,7 @@ __device__ __forceinline__ void shade_light(const KParams& K, Path& P) {
     const v3 lcolor = mk3(L.color[0], L.color[1], L.color[2]);
     float attenuation = (L.posdir[3] == 1.0f) ? L.power / (P.maxDist * P.maxDist) : L.power;
     attenuation *= P.vis;
-    if (M.transparency > 0.0f) {
+    if (GLASS && M.transparency > 0.0f) {
         const float NdotL = fmax_(dot(normal, lightDir), 0.0f);
         if (NdotL <= 0.0f) return;
         const float f0 = pow2_((1.0f - M.ior) / (1.0f + M.ior));
@@ -188,6 +191,7 @@ __device__ __forceinline__ void shade_light(const KParams& K, Path& P) {
 }
 
 // FS:720-769: choose the next direction at the parked surface point and move on.
+template <bool GLASS>
 __device__ __forceinline__ void scatter(const KParams& K, Path& P) {
     const DevMaterial M = K.materials[P.hmat];
     const float fb2 = (float)(P.bounce * P.bounce), fb = (float)P.bounce;
@@ -198,7 +202,7 @@ __device__ __forceinline__ void scatter(const KParams& K, Path& P) {
     const float randVal = rand_(rs);
     const v3 hitNormal = P.hn;
     v3 dir = P.pdir;
-    if (M.transparency > 0.0f) {
+    if (GLASS && M.transparency > 0.0f) {
         const bool entering = dot(-dir, hitNormal) > 0.0f;
         const v3 N = entering ? hitNormal : -hitNormal;
         const float extIor = P.ior;
@@ -242,14 +246,15 @@ __device__ __forceinline__ void scatter(const KParams& K, Path& P) {
 }
 
 // Lighting of the parked point is complete (or there are no lights): FS:717, then scatter.
+template <bool GLASS>
 __device__ __forceinline__ void finish_lighting(const KParams& K, Path& P) {
     P.addLight = P.throughput * P.lacc;
     P.color = P.color + P.addLight;
-    scatter(K, P);
+    scatter<GLASS>(K, P);
 }
 
 // Advance a path by the result of the closest-hit query of its current ray.
-template <bool COUNT>
+template <bool COUNT, bool GLASS = true>
 __device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, const HitRec& h, Tally& c) {
     if (P.mode == MODE_SEGMENT) {
         if (!found) {   // FS:705-711
@@ -264,15 +269,15 @@ __device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, c
         P.hp = h.p; P.hn = h.n; P.hmat = h.mat; P.pdir = P.d;
         if (P.bounce == 0) {                // FS:716-718
             const DevMaterial M = K.materials[h.mat];
-            P.lacc = (M.transparency > 0.0f)
+            P.lacc = (GLASS && M.transparency > 0.0f)
                          ? mk3(0.0f, 0.0f, 0.0f)
                          : mk3(0.05f * M.albedo[0], 0.05f * M.albedo[1], 0.05f * M.albedo[2]);
             P.li = 0;
-            if (K.nLights > 0) { start_light<COUNT>(K, P, c); return; }
-            finish_lighting(K, P);
+            if (K.nLights > 0) { start_light<COUNT, GLASS>(K, P, c); return; }
+            finish_lighting<GLASS>(K, P);
             return;
         }
-        scatter(K, P);
+        scatter<GLASS>(K, P);
         return;
     }
     // MODE_SHADOW: the body of one iteration of FS:511-526
@@ -285,7 +290,7 @@ __device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, c
         else {
             if (COUNT) c.materials += 1;
             const float tr = K.materials[h.mat].transparency;
-            if (tr > 0.0f) { P.vis *= tr; P.o = h.p + P.d * 0.001f; }
+            if (GLASS && tr > 0.0f) { P.vis *= tr; P.o = h.p + P.d * 0.001f; }
             else { P.vis = 0.0f; done = true; lit = false; }
         }
     }
@@ -294,10 +299,10 @@ __device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, c
         if (P.iter < 32 && P.vis > 0.05f) return;   // next iteration: trace again
         lit = P.vis > 0.05f;                         // FS:527
     }
-    if (lit) shade_light(K, P);
+    if (lit) shade_light<GLASS>(K, P);
     P.li += 1;
-    if (P.li < K.nLights) { start_light<COUNT>(K, P, c); return; }
-    finish_lighting(K, P);
+    if (P.li < K.nLights) { start_light<COUNT, GLASS>(K, P, c); return; }
+    finish_lighting<GLASS>(K, P);
 }
 
 }  // namespace rz

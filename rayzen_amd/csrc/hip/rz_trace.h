@@ -53,6 +53,23 @@ struct Tally {          // per-thread counts of the REFERENCE algorithm's memory
 // branch (seen in the ISA: the left child's ref and each triangle's v0 were re-fetched by a dependent load).
 #define RZ_KEEP4(q) asm volatile("" : "+v"((q).x), "+v"((q).y), "+v"((q).z), "+v"((q).w))
 
+// Wave-uniform record fetch through the scalar cache.  In the one-lane-per-sample kernel the 64 lanes of a wave are
+// samples of ONE pixel: primary and shadow rays are near-identical, so most of the time every lane wants the same
+// BVH node.  A vector load of it costs the texture-address unit 16 cycles per dwordx4 (64 lanes x 16 B at 64 B/clk)
+// however many lanes share the address -- measured TA busy 86 % -- while one s_load_dwordx16 fetches the whole
+// 64-B record into SGPRs and leaves the vector memory pipe alone.  The data is read-only for the kernel's lifetime,
+// which is what the (non-coherent) scalar cache needs.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 sload16(const void* p) {
+    f32x16 r;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+    return r;
+}
+#ifndef RZ_SCALAR_UNIFORM
+#define RZ_SCALAR_UNIFORM 1
+#endif
+
 struct HitRec {
     float t;
     v3 p;       // world-space hit point
@@ -134,8 +151,22 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
         while (go && cur >= 0) {
             RZ_SITE(c, 3);
             const float4* __restrict__ pp = reinterpret_cast<const float4*>(pairs + cur);
-            float4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
-            RZ_KEEP4(p0); RZ_KEEP4(p2);
+            float4 p0, p1, p2, p3;
+#if RZ_SCALAR_UNIFORM
+            const DevPair* upp = reinterpret_cast<const DevPair*>(
+                ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)pp >> 32)) << 32) |
+                (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)pp));
+            if (__ballot(reinterpret_cast<const DevPair*>(pp) != upp) == 0ull) {     // every active lane: same pair
+                RZ_SITE(c, 7);
+                const f32x16 q = sload16(upp);
+                p0 = make_float4(q[0], q[1], q[2], q[3]);   p1 = make_float4(q[4], q[5], q[6], q[7]);
+                p2 = make_float4(q[8], q[9], q[10], q[11]); p3 = make_float4(q[12], q[13], q[14], q[15]);
+            } else
+#endif
+            {
+                p0 = pp[0]; p1 = pp[1]; p2 = pp[2]; p3 = pp[3];
+                RZ_KEEP4(p0); RZ_KEEP4(p2);
+            }
             if (COUNT) c.blas_nodes += 2;        // the shader pushes, and later pops, both children
             float tl, tr;
             const bool hl = slab(lo, inv, p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, tl);

@@ -200,3 +200,52 @@ def test_cpp_frontend_example_builds_and_renders(tmp_path):
     assert data.startswith(b"P6\n96 54\n255\n") and len(data) == len(b"P6\n96 54\n255\n") + 96 * 54 * 3
     px = np.frombuffer(data[len(b"P6\n96 54\n255\n"):], np.uint8).reshape(54, 96, 3)
     assert px[0].mean() > 60 and px.std() > 10           # sky on top, not a constant image
+
+
+# ---- the one-lane-per-sample path (scenes without transparent triangles) ------------------------------------
+
+def test_sample_kernel_is_chosen_only_without_transparent_triangles():
+    from rayzen_amd.renderer import Renderer
+    r = Renderer(0)
+    opaque = S.bunny_scene(n=6)
+    r.upload_scene(opaque)
+    r.render_scene(opaque, 32, 24, 2, 3)
+    assert r.last_kernel_name() == "rz_render_samples"
+    glass = S.bunny_scene(n=6, extras=True)                   # a glass blob is in the scene
+    r.upload_scene(glass)
+    r.render_scene(glass, 32, 24, 2, 3)
+    assert r.last_kernel_name() == "rz_render_pixels"
+    # the glass MATERIAL being present in the material array is not enough: a triangle must use it
+    assert (opaque.materials["transparency"] > 0).any()
+    r.close()
+
+
+@pytest.mark.parametrize("spp,chunk", [(1, None), (7, None), (64, None), (130, None), (130, 64), (70, 13)])
+def test_sample_kernel_spp_shapes_and_continuation(spp, chunk):
+    """spp below / at / above a wavefront of samples, and frames continued with sample_base > 0."""
+    sc = S.bunny_scene(n=8)
+    W, H = 40, 24
+    ref = oracle_render(sc, W, H, spp, 4)
+    for backend in ("auto", "pixel"):
+        _eq(hip_render(sc, W, H, spp, 4, chunk=chunk, backend=backend), ref)
+
+
+def test_sample_kernel_tile_sharding_and_counters():
+    sc = S.bunny_scene(n=8)
+    W, H = 72, 40
+    ref, rc = oracle_render(sc, W, H, 3, 4, want_counters=True)
+    full, gc = hip_render(sc, W, H, 3, 4, counted=True)
+    _eq(full, ref)
+    assert gc == rc
+    total = np.zeros_like(full)
+    for r in range(3):
+        total += hip_render(sc, W, H, 3, 4, tile_rank=r, tile_nranks=3)
+    assert (total.view(np.uint32) == full.view(np.uint32)).all()
+
+
+def test_c4_shape_instanced_and_c5_shape_deep_tree_small():
+    """Scaled-down configs[3] (16 instances, shared BLAS, dynamic TLAS) and configs[4] (bigger mesh, 8 bounces)."""
+    c4 = S.instanced_scene(n=12, count=16)
+    _eq(hip_render(c4, 96, 54, 4, 4), oracle_render(c4, 96, 54, 4, 4))
+    c5 = S.stress_scene(n=40)
+    _eq(hip_render(c5, 96, 54, 3, 8), oracle_render(c5, 96, 54, 3, 8))
