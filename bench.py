@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--mesh-n", type=int, default=76, help="bunny stand-in has 12*n*n triangles")
     ap.add_argument("--backend", choices=["auto", "pixel", "wavefront"], default="auto",
                     help="render pipeline: auto = the library's default")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL over xGMI (the real thing); gloo = rehearsal of the N>1 code path on a box with "
+                         "fewer GPUs than ranks (ranks share devices, the reduce is staged through host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (default: min(16, usable cores) = the box's CPU share)")
     ap.add_argument("--cpu-bands", type=int, default=18, help="oracle sample: this many 8-row bands of the frame")
@@ -65,11 +68,15 @@ def main():
         raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if a.dist_backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from rayzen_amd import scene as S
     from rayzen_amd import dist as rzdist
@@ -78,7 +85,7 @@ def main():
     W, H, bounces = a.width, a.height, a.bounces
     spp_total = a.spp * world          # every rank renders ALL samples of its own pixels
     sc = S.bunny_scene(n=a.mesh_n, aspect=W / H)
-    r = Renderer(local_rank, {"auto": 0, "pixel": 1, "wavefront": 2}[a.backend])
+    r = Renderer(dev_index, {"auto": 0, "pixel": 1, "wavefront": 2}[a.backend])
     r.upload_scene(sc)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)    # zero outside this rank's tiles
     stream = torch.cuda.Stream(dev)     # the kernels, the reduce and the fences all order on this stream
@@ -91,7 +98,13 @@ def main():
     def step():
         r.render()                      # async on torch's current stream
         if world > 1:
-            rzdist.reduce_accum(accum, dst=0)
+            if a.dist_backend == "nccl":
+                rzdist.reduce_accum(accum, dst=0)          # one RCCL reduce(SUM) of the 33 MB frame
+            else:                                           # rehearsal: same reduce, staged through the host
+                host = accum.cpu()
+                rzdist.reduce_accum(host, dst=0)
+                if rank == 0:
+                    accum.copy_(host)
 
     def fence():
         if world > 1:
@@ -118,7 +131,7 @@ def main():
     kms = float(np.mean(kernel_ms))
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -133,7 +146,7 @@ def main():
                                f"incl. floor) {W}x{H}, {a.spp} spp per GPU ({spp_total} spp total), {bounces} bounces, "
                                f"2 lights", "width": W, "height": H, "spp_per_gpu": a.spp, "spp_total": spp_total,
                    "bounces": bounces, "triangles": int(sc.arrays[S.BIND_TRIANGLES].shape[0]),
-                   "parallelism": f"tiles8x8-roundrobin-x{world}" + ("+rccl-reduce" if world > 1 else "")},
+                   "parallelism": f"tiles8x8-roundrobin-x{world}" + (("+rccl-reduce" if a.dist_backend == "nccl" else "+gloo-reduce(rehearsal)") if world > 1 else "")},
     }
     if rank == 0:
         ach = alg_bytes / (kms * 1e-3) / 1e9

@@ -30,7 +30,6 @@ void dump_wave_log(int nWaves);
 #endif
 void launch_render_pixels(const KParams& K, bool counted, hipStream_t stream);
 void launch_render_samples(const KParams& K, bool counted, hipStream_t stream);
-void launch_sum_samples(const KParams& K, bool first, bool countPixels, hipStream_t stream);
 void launch_resolve(const float4* accum, uchar4* out, int n, hipStream_t stream);
 }  // namespace rz
 
@@ -106,7 +105,7 @@ struct rz_ctx {
     rz_frame_params frame{};
     DevBuf ownAccum, dIor;
     // queued pipeline (rz_wavefront.hip)
-    DevBuf wfState, wfQueues, wfCounts, dContrib;
+    DevBuf wfState, wfQueues, wfCounts;
     bool sceneHasTransparency = true;   // some triangle uses a material with transparency > 0
     int wfSlots = 0;
     int wfTraceBlocks = 0;
@@ -439,31 +438,10 @@ bool use_samples(const rz_ctx* c) {
 
 int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     K.nSlots = K.nLocalTiles * 64;
-    if (K.nSlots <= 0) {
-        RZ_HIP(c, hipEventRecord(c->evStart[evSlot], c->stream));
-        RZ_HIP(c, hipEventRecord(c->evStop[evSlot], c->stream));
-        c->lastLaunches = 0;
-        return RZ_OK;
-    }
-    // the contribution buffer holds `chunk` samples per owned pixel; bound it to ~6 GiB
-    const size_t perSample = (size_t)K.nSlots * 32;
-    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)K.spp, ((size_t)6 << 30) / perSample));
-    if (chunk >= 64) chunk = chunk / 64 * 64;       // whole waves per pixel
-    int rc = ensure(c, c->dContrib, perSample * (size_t)chunk);
-    if (rc != RZ_OK) return rc;
-    K.contrib = static_cast<float4*>(c->dContrib.p);
-    const int base0 = K.sampleBase, total = K.spp;
-    int launches = 0;
     RZ_HIP(c, hipEventRecord(c->evStart[evSlot], c->stream));
-    for (int done = 0; done < total; done += chunk) {
-        K.chunkSpp = std::min(chunk, total - done);
-        K.sampleBase = base0 + done;
-        launch_render_samples(K, counted, c->stream);
-        if (done + chunk >= total) RZ_HIP(c, hipEventRecord(c->evStop[evSlot], c->stream));
-        launch_sum_samples(K, base0 == 0 && done == 0, counted && done == 0, c->stream);
-        launches += 2;
-    }
-    c->lastLaunches = launches;
+    if (K.nSlots > 0) launch_render_samples(K, counted, c->stream);
+    RZ_HIP(c, hipEventRecord(c->evStop[evSlot], c->stream));
+    c->lastLaunches = K.nSlots > 0 ? 1 : 0;
     return RZ_OK;
 }
 
@@ -508,7 +486,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     std::memcpy(K.invView, f.inv_view, 64);
     std::memcpy(K.invProj, f.inv_proj, 64);
     std::memcpy(K.camPos, f.cam_pos, 12);
-    const size_t perWave = (size_t)K.blasStackCap * 512 + (size_t)K.tlasStackCap * 256;
+    const size_t perWave = (size_t)K.blasStackCap * 512 + (size_t)K.tlasStackCap * 256 + 2048;
     if (perWave * 4 > 160 * 1024)   // sized for the largest (4-wave) workgroup
         return fail(c, RZ_ERR_BAD_SCENE, "BLAS depth %d needs %zu B of LDS stack per wave; the limit is %d", c->maxBlasDepth, perWave, 40 * 1024);
     if (counted) {
@@ -614,7 +592,7 @@ void rz_destroy(rz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
-                      &c->dCounters, &c->dResolve, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts, &c->dContrib})
+                      &c->dCounters, &c->dResolve, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts})
         b->release();
     if (c->wfHostCount) (void)hipHostFree(c->wfHostCount);
     for (int i = 0; i < rz_ctx::kRing; ++i) {

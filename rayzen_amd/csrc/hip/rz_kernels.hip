@@ -132,11 +132,14 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
 // ---------------------------------------------------------------------------------------------------------
 // rz_render_samples<COUNT>: one lane per SAMPLE.  Valid when no triangle of the scene uses a transparent
 // material: then FS:674's currentIor never leaves 1.0 and the only coupling between a pixel's samples is the ORDER
-// of the colour additions (FS:717 then FS:709, sample after sample).  Each lane runs one sample's path and stores
-// its two addends; rz_sum_samples replays the additions in the shader's order, so the sum is bit-identical.
-//   item = slot * chunkSpp + s (s fastest): a wave's 64 lanes are consecutive samples of one pixel (spp >= 64), so
-//   primary and shadow rays of a wave are near-identical -- uniform traversal, L1 broadcast instead of 64
-//   divergent lines -- and a heavy pixel costs ONE sample's latency instead of spp of them: no tail.
+// of the colour additions (FS:717 then FS:709, sample after sample).
+//   * a wavefront owns whole pixels: ONE pixel, walked in batches of 64 samples, when spp >= 64; floor(64/spp)
+//     pixels otherwise.  Its lanes are therefore samples of the same pixel(s): primary and shadow rays of a wave
+//     are near-identical -- uniform traversal, scalar-cache node fetches (rz_trace.h) -- and a heavy pixel costs
+//     ONE sample's latency per batch instead of spp of them in a row: the 84-ms tail of the per-pixel kernel is gone;
+//   * each lane runs one sample's path and parks its two addends in LDS (2 KB per wave); one lane per pixel then
+//     replays `color += light; color += sky` in sample order, so the sum is bit-identical to the shader's.
+//     Nothing but the final pixel value goes to HBM.
 #ifndef RZ_SAMPLES_MIN_WAVES
 #define RZ_SAMPLES_MIN_WAVES 3   // measured on C2: 2 -> 29.0 ms, 3 -> 22.1 ms, 4 -> 22.1 ms (the kernel is issue-bound; a third wave overlaps scalar/VMEM/LDS issue with VALU)
 #endif
@@ -146,94 +149,146 @@ __global__ __launch_bounds__(64, RZ_SAMPLES_MIN_WAVES) void rz_render_samples(co
     const int lane = threadIdx.x & 63;
     uint2* bstk = reinterpret_cast<uint2*>(lds_raw) + lane;
     int* tstk = reinterpret_cast<int*>(lds_raw + (size_t)K.blasStackCap * 64 * sizeof(uint2)) + lane;
-    const long long item = (long long)blockIdx.x * 64 + lane;
-    const long long nItems = (long long)K.nSlots * K.chunkSpp;
-    Tally c = {};
+    float4* addL = reinterpret_cast<float4*>(lds_raw + (size_t)K.blasStackCap * 64 * sizeof(uint2) +
+                                             (size_t)K.tlasStackCap * 64 * sizeof(int));
+    float4* addS = addL + 64;
+
+    const int spp = K.spp;
+    const int pixPerWave = spp >= 64 ? 1 : 64 / spp;
+    const int nBatches = spp >= 64 ? (spp + 63) / 64 : 1;
+    // this lane's pixel (as a path-tracing lane) and this lane's pixel as a summing lane (lanes 0..pixPerWave-1)
+    const int myPixInWave = spp >= 64 ? 0 : lane / spp;
+    const int slot = blockIdx.x * pixPerWave + myPixInWave;
+    const int sumSlot = blockIdx.x * pixPerWave + lane;
+    bool inside = false, sumInside = false;
+    size_t sumPix = 0;
     Path P;
-    P.mode = MODE_DONE;
-    bool active = false;
-    if (item < nItems) {
-        const int slot = (int)(item / K.chunkSpp), s = (int)(item - (long long)slot * K.chunkSpp);
+    if (slot < K.nSlots && myPixInWave < pixPerWave) {
         const int localTile = slot >> 6, l = slot & 63;
         const int tile = localTile * K.tileNRanks + K.tileRank;
         const int tx = tile % K.tilesX, ty = tile / K.tilesX;
         const int px = tx * RZ_TILE_W + (l & 7), py = ty * RZ_TILE_H + (l >> 3);
         if (px < K.width && py < K.height) {
-            active = true;
+            inside = true;
             const float fragx = (float)px + 0.5f, fragy = (float)py + 0.5f;
             P.uv.x = fragx / (float)K.width;
             P.uv.y = fragy / (float)K.height;
             P.fragSum = fragx + fragy;
+        }
+    }
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (lane < pixPerWave && sumSlot < K.nSlots) {
+        const int localTile = sumSlot >> 6, l = sumSlot & 63;
+        const int tile = localTile * K.tileNRanks + K.tileRank;
+        const int tx = tile % K.tilesX, ty = tile / K.tilesX;
+        const int px = tx * RZ_TILE_W + (l & 7), py = ty * RZ_TILE_H + (l >> 3);
+        if (px < K.width && py < K.height) {
+            sumInside = true;
+            sumPix = (size_t)py * K.width + px;
+            if (K.sampleBase != 0) acc = K.accum[sumPix];
+        }
+    }
+    // spp >= 64: the wave's single pixel, summed per channel by lanes 0..2 (lane 3 keeps the sample count)
+    const bool sumInside0 = __shfl((int)sumInside, 0) != 0;
+    const size_t sumPix0 = ((size_t)(unsigned)__shfl((int)(sumPix >> 32), 0) << 32) | (unsigned)__shfl((int)(unsigned)sumPix, 0);
+    float chan = 0.0f, alpha0 = 0.0f;
+    if (spp >= 64 && sumInside0 && K.sampleBase != 0) {
+        const float ax = __shfl(acc.x, 0), ay = __shfl(acc.y, 0), az = __shfl(acc.z, 0);
+        chan = lane == 0 ? ax : (lane == 1 ? ay : az);
+        alpha0 = __shfl(acc.w, 0);
+    }
+    Tally c = {};
+#ifdef RZ_PROF
+    unsigned long long tTrace = 0, tAdv = 0;
+#endif
+    for (int b = 0; b < nBatches; ++b) {
+        const int s = spp >= 64 ? b * 64 + lane : lane - myPixInWave * spp;
+        P.mode = MODE_DONE;
+        P.addLight = mk3(0.0f, 0.0f, 0.0f);
+        P.addSky = mk3(0.0f, 0.0f, 0.0f);
+        if (inside && s < spp) {
             P.color = mk3(0.0f, 0.0f, 0.0f);
             P.ior = 1.0f;
             P.samp = K.sampleBase + s;
             begin_sample<COUNT>(K, P, c);
         }
+        while (P.mode != MODE_DONE) {
+#ifdef RZ_PROF
+            RZ_SITE(c, 6);
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+            HitRec h;
+            const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, c);
+#ifdef RZ_PROF
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
+            advance<COUNT, false>(K, P, found, h, c);
+#ifdef RZ_PROF
+            tTrace += t2 - t1; tAdv += __builtin_amdgcn_s_memtime() - t2;
+#endif
+        }
+        // park the addends (zeros for idle lanes: adding +0 is exact), then replay the adds in sample order
+        addL[lane] = make_float4(P.addLight.x, P.addLight.y, P.addLight.z, 0.0f);
+        addS[lane] = make_float4(P.addSky.x, P.addSky.y, P.addSky.z, 0.0f);
+        __syncthreads();
+        if (spp >= 64) {
+            // one pixel per wave: the three colour channels are independent chains -> lanes 0,1,2 take one each
+            // (a 128-add dependent chain per batch instead of 384 on one lane)
+            if (lane < 3 && sumInside0) {
+                const float* Lf = reinterpret_cast<const float*>(addL) + lane;
+                const float* Sf = reinterpret_cast<const float*>(addS) + lane;
+                const int n = min(64, spp - b * 64);
+                int k = 0;
+                for (; k + 8 <= n; k += 8) {
+                    float l[8], q[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { l[u] = Lf[4 * (k + u)]; q[u] = Sf[4 * (k + u)]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { chan = chan + l[u]; chan = chan + q[u]; }   // FS:717, FS:709
+                }
+                for (; k < n; ++k) { chan = chan + Lf[4 * k]; chan = chan + Sf[4 * k]; }
+            }
+        } else if (sumInside) {
+            const int first = lane * spp;
+            for (int k = 0; k < spp; ++k) {
+                const float4 L = addL[first + k], S = addS[first + k];
+                acc.x = acc.x + L.x; acc.y = acc.y + L.y; acc.z = acc.z + L.z;     // FS:717
+                acc.x = acc.x + S.x; acc.y = acc.y + S.y; acc.z = acc.z + S.z;     // FS:709
+            }
+        }
+        __syncthreads();
+    }
+    if (spp >= 64) {
+        if (sumInside0) {
+            float* out = reinterpret_cast<float*>(&K.accum[sumPix0]);
+            if (lane < 3) out[lane] = chan;
+            else if (lane == 3) { out[3] = alpha0 + (float)spp; K.ior[sumPix0] = 1.0f; }
+        }
+    } else if (sumInside) {
+        acc.w += (float)spp;
+        K.accum[sumPix] = acc;
+        K.ior[sumPix] = 1.0f;
     }
 #ifdef RZ_PROF
-    unsigned long long tTrace = 0, tAdv = 0;
-    while (P.mode != MODE_DONE) {
-        RZ_SITE(c, 6);
-        unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        HitRec h;
-        const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, c);
-        unsigned long long t2 = __builtin_amdgcn_s_memtime();
-        advance<COUNT, false>(K, P, found, h, c);
-        tTrace += t2 - t1; tAdv += __builtin_amdgcn_s_memtime() - t2;
-    }
     if (COUNT) {
         unsigned long long* pr = reinterpret_cast<unsigned long long*>(K.counters + 1);
         for (int k = 0; k < 16; ++k) if (c.p[k]) atomicAdd(&pr[k], (unsigned long long)c.p[k]);
         if (lane == 0) { atomicAdd(&pr[17], tTrace); atomicAdd(&pr[18], tAdv); }
     }
-#else
-    while (P.mode != MODE_DONE) {
-        HitRec h;
-        const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, c);
-        advance<COUNT, false>(K, P, found, h, c);
-    }
 #endif
-    if (active) {
-        K.contrib[2 * item] = make_float4(P.addLight.x, P.addLight.y, P.addLight.z, 0.0f);
-        K.contrib[2 * item + 1] = make_float4(P.addSky.x, P.addSky.y, P.addSky.z, 0.0f);
-    }
     if (COUNT) {
-        DevCounters* g = K.counters;
-        atomicAdd(&g->samples, (unsigned long long)c.samples);
-        atomicAdd(&g->traversals, (unsigned long long)c.traversals);
-        atomicAdd(&g->tlas_nodes, (unsigned long long)c.tlas_nodes);
-        atomicAdd(&g->tlas_leaf_indices, (unsigned long long)c.tlas_leaf_indices);
-        atomicAdd(&g->instances, (unsigned long long)c.instances);
-        atomicAdd(&g->blas_nodes, (unsigned long long)c.blas_nodes);
-        atomicAdd(&g->triangles, (unsigned long long)c.triangles);
-        atomicAdd(&g->materials, (unsigned long long)c.materials);
-        atomicAdd(&g->light_fetches, (unsigned long long)c.light_fetches);
+        // one atomic per counter per wave: reduce across lanes first
+        unsigned v[9] = {c.samples, c.traversals, c.tlas_nodes, c.tlas_leaf_indices, c.instances, c.blas_nodes,
+                         c.triangles, c.materials, c.light_fetches};
+        unsigned long long* g = reinterpret_cast<unsigned long long*>(K.counters);
+        for (int k = 0; k < 9; ++k) {
+            unsigned x = v[k];
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+            if (lane == 0 && x) atomicAdd(&g[k], (unsigned long long)x);
+        }
+        const unsigned long long pm = __ballot(sumInside);   // lanes 0..pixPerWave-1 (lane 0 alone when spp >= 64)
+        if (lane == 0 && pm) atomicAdd(&K.counters->pixels, (unsigned long long)__popcll(pm));
     }
-}
-
-// Replays FS:709/717's `color +=` in sample order for every owned pixel (one lane per pixel), starting from the
-// colour already in the accumulation buffer.  first: this is the first chunk of the frame (sample_base == 0 and
-// chunk 0) -> start from zero.  last: add spp to the sample count.
-__global__ __launch_bounds__(256) void rz_sum_samples(const KParams K, const int first, const int countPixels) {
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= K.nSlots) return;
-    const int localTile = slot >> 6, l = slot & 63;
-    const int tile = localTile * K.tileNRanks + K.tileRank;
-    const int tx = tile % K.tilesX, ty = tile / K.tilesX;
-    const int px = tx * RZ_TILE_W + (l & 7), py = ty * RZ_TILE_H + (l >> 3);
-    if (px >= K.width || py >= K.height) return;
-    const size_t pix = (size_t)py * K.width + px;
-    float4 a = first ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : K.accum[pix];
-    const float4* __restrict__ cp = K.contrib + 2 * (size_t)slot * K.chunkSpp;
-    for (int s = 0; s < K.chunkSpp; ++s) {
-        const float4 L = cp[2 * s], S = cp[2 * s + 1];
-        a.x = a.x + L.x; a.y = a.y + L.y; a.z = a.z + L.z;
-        a.x = a.x + S.x; a.y = a.y + S.y; a.z = a.z + S.z;
-    }
-    a.w += (float)K.chunkSpp;
-    K.accum[pix] = a;
-    K.ior[pix] = 1.0f;
-    if (countPixels) atomicAdd(&K.counters->pixels, 1ull);
 }
 
 // FS:772-773 + 8-bit quantisation: rgba8 = round(clamp(sum / n, 0, 1) * 255), a = 255.
@@ -287,20 +342,15 @@ void dump_wave_log(int nWaves) {
 #endif
 
 void launch_render_samples(const KParams& K, bool counted, hipStream_t stream) {
-    const long long nItems = (long long)K.nSlots * K.chunkSpp;
-    const long long blocks = (nItems + 63) / 64;
+    const int pixPerWave = K.spp >= 64 ? 1 : 64 / K.spp;
+    const long long blocks = ((long long)K.nSlots + pixPerWave - 1) / pixPerWave;
     if (blocks <= 0) return;
-    const size_t lds = (size_t)K.blasStackCap * 64 * sizeof(uint2) + (size_t)K.tlasStackCap * 64 * sizeof(int);
+    const size_t lds = (size_t)K.blasStackCap * 64 * sizeof(uint2) + (size_t)K.tlasStackCap * 64 * sizeof(int) +
+                       2 * 64 * sizeof(float4);
     if (counted)
         hipLaunchKernelGGL(rz_render_samples<true>, dim3((unsigned)blocks), dim3(64), lds, stream, K);
     else
         hipLaunchKernelGGL(rz_render_samples<false>, dim3((unsigned)blocks), dim3(64), lds, stream, K);
-}
-
-void launch_sum_samples(const KParams& K, bool first, bool countPixels, hipStream_t stream) {
-    if (K.nSlots <= 0) return;
-    hipLaunchKernelGGL(rz_sum_samples, dim3((K.nSlots + 255) / 256), dim3(256), 0, stream, K, first ? 1 : 0,
-                       countPixels ? 1 : 0);
 }
 
 void launch_resolve(const float4* accum, uchar4* out, int n, hipStream_t stream) {

@@ -83,7 +83,6 @@ struct KParams {
     float4* accum;          // width*height RGBA32F, row 0 = bottom
     float* ior;             // width*height: FS:674's currentIor carried across rz_render calls
     DevCounters* counters;  // only for the counting build
-    float4* contrib;        // one-lane-per-sample mode: [item][2] = {FS:717 addend, FS:709 addend}, item = slot*chunkSpp + s
     int32_t nTlasNodes;
     int32_t nLights;        // min(numLights uniform, lights.length())  (FS:574-575)
     int32_t nMaterials;
@@ -93,7 +92,6 @@ struct KParams {
     int32_t tileRank, tileNRanks;
     int32_t maxBounces;
     int32_t spp, sampleBase;
-    int32_t chunkSpp;       // samples per pixel in the contribution buffer (one-lane-per-sample mode)
     int32_t nSlots;         // nLocalTiles * 64
     int32_t blasStackCap;   // LDS entries per lane for the BLAS stack (>= max BLAS depth)
     int32_t tlasStackCap;
