@@ -68,26 +68,33 @@ __device__ __forceinline__ v3 xform_normal(const float* m, v3 v) {
 }
 
 // ---- sin / cos / acos -----------------------------------------------------
+// A binary64 literal cannot be an inline operand on gfx950, so hipcc materialises each one in a register pair -- and,
+// left alone, hoists all ~24 of them out of the sample loop and keeps them in VGPRs across the whole BVH walk
+// (measured: the fused kernel wanted 193 VGPRs where trace and shading need 82 and 84 on their own).  KD() pins a
+// constant to an SGPR pair created where it is used (two s_mov_b32 on the scalar unit; v_fma_f64 takes one scalar
+// operand) and, being volatile, stays inside the function.
+__device__ __forceinline__ double KD(double v) { asm volatile("" : "+s"(v)); return v; }
+
 struct SinCos { double s, c; int q; };
 
 __device__ __forceinline__ SinCos sincos_core(float xf) {
     const double x = (double)xf;
-    const double k = __builtin_rint(x * 6.36619772367581382433e-01);
-    double r = __builtin_fma(-k, 1.57079632673412561417e+00, x);
-    r = __builtin_fma(-k, 6.07710050630396597660e-11, r);
-    r = __builtin_fma(-k, 2.02226624871116645580e-21, r);
+    const double k = __builtin_rint(x * KD(6.36619772367581382433e-01));
+    double r = __builtin_fma(-k, KD(1.57079632673412561417e+00), x);
+    r = __builtin_fma(-k, KD(6.07710050630396597660e-11), r);
+    r = __builtin_fma(-k, KD(2.02226624871116645580e-21), r);
     const double q = k - 4.0 * __builtin_floor(k * 0.25);
     const double z = r * r;
-    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
-    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    double ps = __builtin_fma(z, KD(1.58969099521155010221e-10), KD(-2.50507602534068634195e-08));
+    ps = __builtin_fma(z, ps, KD(2.75573137070700676789e-06));
+    ps = __builtin_fma(z, ps, KD(-1.98412698298579493134e-04));
+    ps = __builtin_fma(z, ps, KD(8.33333333332248946124e-03));
+    ps = __builtin_fma(z, ps, KD(-1.66666666666666324348e-01));
+    double pc = __builtin_fma(z, KD(-1.13596475577881948265e-11), KD(2.08757232129817482790e-09));
+    pc = __builtin_fma(z, pc, KD(-2.75573143513906633035e-07));
+    pc = __builtin_fma(z, pc, KD(2.48015872894767294178e-05));
+    pc = __builtin_fma(z, pc, KD(-1.38888888888741095749e-03));
+    pc = __builtin_fma(z, pc, KD(4.16666666666666019037e-02));
     SinCos o;
     o.s = __builtin_fma(z * r, ps, r);
     o.c = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
@@ -111,28 +118,28 @@ __device__ __forceinline__ float acos_(float xf) {
     const double ax = __builtin_fabs(x);
     if (!(ax < 1.0)) {
         if (x != x) return xf;
-        return (x > 0.0) ? 0.0f : (float)3.14159265358979311600e+00;
+        return (x > 0.0) ? 0.0f : (float)KD(3.14159265358979311600e+00);
     }
     const bool small = ax < 0.5;
     const double z = small ? x * x : (1.0 - ax) * 0.5;
-    double p = __builtin_fma(z, 3.47933107596021167570e-05, 7.91534994289814532176e-04);
-    p = __builtin_fma(z, p, -4.00555345006794114027e-02);
-    p = __builtin_fma(z, p, 2.01212532134862925881e-01);
-    p = __builtin_fma(z, p, -3.25565818622400915405e-01);
-    p = __builtin_fma(z, p, 1.66666666666666657415e-01);
+    double p = __builtin_fma(z, KD(3.47933107596021167570e-05), KD(7.91534994289814532176e-04));
+    p = __builtin_fma(z, p, KD(-4.00555345006794114027e-02));
+    p = __builtin_fma(z, p, KD(2.01212532134862925881e-01));
+    p = __builtin_fma(z, p, KD(-3.25565818622400915405e-01));
+    p = __builtin_fma(z, p, KD(1.66666666666666657415e-01));
     p = p * z;
-    double q = __builtin_fma(z, 7.70381505559019352791e-02, -6.88283971605453293030e-01);
-    q = __builtin_fma(z, q, 2.02094576023350569471e+00);
-    q = __builtin_fma(z, q, -2.40339491173441421878e+00);
+    double q = __builtin_fma(z, KD(7.70381505559019352791e-02), KD(-6.88283971605453293030e-01));
+    q = __builtin_fma(z, q, KD(2.02094576023350569471e+00));
+    q = __builtin_fma(z, q, KD(-2.40339491173441421878e+00));
     q = __builtin_fma(z, q, 1.0);
     const double R = p / q;
     double res;
     if (small) {
-        res = 1.57079632679489655800e+00 - __builtin_fma(x, R, x);
+        res = KD(1.57079632679489655800e+00) - __builtin_fma(x, R, x);
     } else {
         const double s = __builtin_sqrt(z);
         const double t = 2.0 * __builtin_fma(s, R, s);
-        res = (x > 0.0) ? t : 3.14159265358979311600e+00 - t;
+        res = (x > 0.0) ? t : KD(3.14159265358979311600e+00) - t;
     }
     return (float)res;
 }

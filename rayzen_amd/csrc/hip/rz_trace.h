@@ -125,6 +125,18 @@ __device__ __forceinline__ v3 x34_normal(const float* m, v3 v) {   // mat3(trans
                (m[6] * v.x + m[7] * v.y) + m[8] * v.z);
 }
 
+// Pop one stack entry.  The shader's cull `tmin > tHit` (FS:430) is evaluated here, against the CURRENT tLoc; a
+// culled entry becomes an empty leaf (enc -1 = ~((0 << 4) | 0)): the next leaf phase tests none of its zero
+// triangles and pops again.  Same visits in the same order, without an inner pop-until-unculled loop.
+__device__ __forceinline__ bool pop_entry(uint2* bstk, int& sp, float tLoc, int& cur) {
+    if (sp <= 0) return false;
+    --sp;
+    uint2 e = bstk[sp * 64];
+    asm volatile("" : "+v"(e.x), "+v"(e.y));     // one ds_read_b64
+    cur = (__uint_as_float(e.y) > tLoc) ? -1 : (int)e.x;
+    return true;
+}
+
 // One instance's BLAS (FS:419-454) in the instance's local space.
 // bstk: this lane's column of the LDS stack, entries 64 apart.
 // Returns the winning triangle (absolute DevTri index) or -1; tLoc = its t.
@@ -150,50 +162,44 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
     while (go) {
         while (go && cur >= 0) {
             RZ_SITE(c, 3);
-            const float4* __restrict__ pp = reinterpret_cast<const float4*>(pairs + cur);
-            float4 p0, p1, p2, p3;
+            const DevPair* pp = pairs + cur;
+            if (COUNT) c.blas_nodes += 2;        // the shader pushes, and later pops, both children
+            float tl, tr;
+            bool hl, hr;
+            int lenc, renc;
 #if RZ_SCALAR_UNIFORM
             const DevPair* upp = reinterpret_cast<const DevPair*>(
                 ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)pp >> 32)) << 32) |
                 (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)pp));
-            if (__ballot(reinterpret_cast<const DevPair*>(pp) != upp) == 0ull) {     // every active lane: same pair
-                RZ_SITE(c, 7);
+            if (__ballot(pp != upp) == 0ull) {       // every active lane wants the same pair: one scalar fetch,
+                RZ_SITE(c, 7);                        // box values consumed straight from SGPRs
                 const f32x16 q = sload16(upp);
-                p0 = make_float4(q[0], q[1], q[2], q[3]);   p1 = make_float4(q[4], q[5], q[6], q[7]);
-                p2 = make_float4(q[8], q[9], q[10], q[11]); p3 = make_float4(q[12], q[13], q[14], q[15]);
+                hl = slab(lo, inv, q[0], q[1], q[2], q[4], q[5], q[6], tl);
+                hr = slab(lo, inv, q[8], q[9], q[10], q[12], q[13], q[14], tr);
+                lenc = __float_as_int(q[3]);
+                renc = __float_as_int(q[11]);
             } else
 #endif
             {
-                p0 = pp[0]; p1 = pp[1]; p2 = pp[2]; p3 = pp[3];
+                const float4* __restrict__ p4 = reinterpret_cast<const float4*>(pp);
+                float4 p0 = p4[0], p1 = p4[1], p2 = p4[2], p3 = p4[3];
                 RZ_KEEP4(p0); RZ_KEEP4(p2);
+                hl = slab(lo, inv, p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, tl);
+                hr = slab(lo, inv, p2.x, p2.y, p2.z, p3.x, p3.y, p3.z, tr);
+                lenc = __float_as_int(p0.w);
+                renc = __float_as_int(p2.w);
             }
-            if (COUNT) c.blas_nodes += 2;        // the shader pushes, and later pops, both children
-            float tl, tr;
-            const bool hl = slab(lo, inv, p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, tl);
-            const bool hr = slab(lo, inv, p2.x, p2.y, p2.z, p3.x, p3.y, p3.z, tr);
             if (hl) {
-                bstk[sp * 64] = make_uint2((unsigned)__float_as_int(p0.w), __float_as_uint(tl));
+                bstk[sp * 64] = make_uint2((unsigned)lenc, __float_as_uint(tl));
                 ++sp;
             }
-            if (hr && !(tr > tLoc)) {
-                cur = __float_as_int(p2.w);
-            } else {
-                go = false;
-                while (sp > 0) {
-                    --sp;
-                    uint2 e = bstk[sp * 64];
-                    asm volatile("" : "+v"(e.x), "+v"(e.y));     // one ds_read_b64, not two b32 with a second wait
-                    if (__uint_as_float(e.y) > tLoc) continue;
-                    cur = (int)e.x;
-                    go = true;
-                    break;
-                }
-            }
+            if (hr && !(tr > tLoc)) cur = renc;
+            else go = pop_entry(bstk, sp, tLoc, cur);
             if (__popcll(__ballot(go && cur >= 0)) < RZ_DESCEND_MIN_LANES) break;
         }
         if (go && cur < 0) {
             RZ_SITE(c, 1);
-            // leaf: <= 4 triangles, contiguous in leaf order, tested in order
+            // leaf: <= 4 triangles, contiguous in leaf order, tested in order (count 0: a culled stack entry)
             const int v = ~cur;
             const int first = v >> 4, count = v & 15;
             if (COUNT) c.triangles += (unsigned)count;
@@ -207,17 +213,7 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
                     if (t < tLoc) { tLoc = t; best = first + i; }
                 }
             }
-            // pop until an entry survives the cull against the current tLoc
-            go = false;
-            while (sp > 0) {
-                --sp;
-                uint2 e = bstk[sp * 64];
-                asm volatile("" : "+v"(e.x), "+v"(e.y));
-                if (__uint_as_float(e.y) > tLoc) continue;
-                cur = (int)e.x;
-                go = true;
-                break;
-            }
+            go = pop_entry(bstk, sp, tLoc, cur);
         }
         RZ_SITE(c, 0);
     }
