@@ -29,7 +29,7 @@ namespace rz {
 void dump_wave_log(int nWaves);
 #endif
 void launch_render_pixels(const KParams& K, bool counted, hipStream_t stream);
-void launch_render_samples(const KParams& K, bool counted, hipStream_t stream);
+void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream_t stream);
 void launch_resolve(const float4* accum, uchar4* out, int n, hipStream_t stream);
 }  // namespace rz
 
@@ -430,16 +430,14 @@ int render_wavefront(rz_ctx* c, const KParams& K, bool counted) {
     return RZ_OK;
 }
 
-// One lane per sample is exact only while FS:674's currentIor cannot change, i.e. no triangle is transparent.
-bool use_samples(const rz_ctx* c) {
-    if (c->flags & RZ_FLAG_MEGAKERNEL) return false;
-    return !c->sceneHasTransparency;
-}
+// One lane per sample: independent samples when no triangle is transparent, speculated currentIor otherwise
+// (rz_kernels.hip).  The one-lane-per-pixel kernel remains as RZ_FLAG_MEGAKERNEL (the literal, sequential form).
+bool use_samples(const rz_ctx* c) { return (c->flags & RZ_FLAG_MEGAKERNEL) == 0; }
 
 int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     K.nSlots = K.nLocalTiles * 64;
     RZ_HIP(c, hipEventRecord(c->evStart[evSlot], c->stream));
-    if (K.nSlots > 0) launch_render_samples(K, counted, c->stream);
+    if (K.nSlots > 0) launch_render_samples(K, counted, c->sceneHasTransparency, c->stream);
     RZ_HIP(c, hipEventRecord(c->evStop[evSlot], c->stream));
     c->lastLaunches = K.nSlots > 0 ? 1 : 0;
     return RZ_OK;
@@ -507,7 +505,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     } else if (use_samples(c)) {
         rc = render_samples(c, K, counted, slot);
         if (rc != RZ_OK) return rc;
-        c->lastKernel = "rz_render_samples";
+        c->lastKernel = c->sceneHasTransparency ? "rz_render_samples<glass>" : "rz_render_samples";
     } else {
         RZ_HIP(c, hipEventRecord(c->evStart[slot], c->stream));
         launch_render_pixels(K, counted, c->stream);

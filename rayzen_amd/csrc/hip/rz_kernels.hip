@@ -130,9 +130,15 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// rz_render_samples<COUNT>: one lane per SAMPLE.  Valid when no triangle of the scene uses a transparent
-// material: then FS:674's currentIor never leaves 1.0 and the only coupling between a pixel's samples is the ORDER
-// of the colour additions (FS:717 then FS:709, sample after sample).
+// rz_render_samples<COUNT, GLASS>: one lane per SAMPLE.  The shader couples a pixel's samples in two ways only: the
+// ORDER of the colour additions (FS:717 then FS:709, sample after sample) and FS:674's currentIor, which is declared
+// outside the sample loop and is read / written only where a path scatters at a transparent surface (FS:727-742).
+//   GLASS = false (no triangle uses a transparent material): currentIor never leaves 1.0; samples are independent.
+//   GLASS = true: the samples of a pixel run in parallel SPECULATING the incoming currentIor; each lane records
+//     whether it read it (usedIor) and what it left (P.ior).  A ballot scan then walks the samples in order: the
+//     first sample that read currentIor after an earlier one changed it was computed from a wrong value -- every
+//     sample before it is final, it and its successors are re-run with the corrected value, and so on.  A lane's
+//     final result is computed from exactly the currentIor the sequential shader would have given it.
 //   * a wavefront owns whole pixels: ONE pixel, walked in batches of 64 samples, when spp >= 64; floor(64/spp)
 //     pixels otherwise.  Its lanes are therefore samples of the same pixel(s): primary and shadow rays of a wave
 //     are near-identical -- uniform traversal, scalar-cache node fetches (rz_trace.h) -- and a heavy pixel costs
@@ -143,7 +149,16 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
 #ifndef RZ_SAMPLES_MIN_WAVES
 #define RZ_SAMPLES_MIN_WAVES 3   // measured on C2: 2 -> 29.0 ms, 3 -> 22.1 ms, 4 -> 22.1 ms (the kernel is issue-bound; a third wave overlaps scalar/VMEM/LDS issue with VALU)
 #endif
-template <bool COUNT>
+__device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
+    a.traversals += b.traversals; a.tlas_nodes += b.tlas_nodes; a.tlas_leaf_indices += b.tlas_leaf_indices;
+    a.instances += b.instances; a.blas_nodes += b.blas_nodes; a.triangles += b.triangles; a.materials += b.materials;
+    a.light_fetches += b.light_fetches; a.samples += b.samples;
+#ifdef RZ_PROF
+    for (int k = 0; k < 16; ++k) a.p[k] += b.p[k];
+#endif
+}
+
+template <bool COUNT, bool GLASS>
 __global__ __launch_bounds__(64, RZ_SAMPLES_MIN_WAVES) void rz_render_samples(const KParams K) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
@@ -188,6 +203,11 @@ __global__ __launch_bounds__(64, RZ_SAMPLES_MIN_WAVES) void rz_render_samples(co
             if (K.sampleBase != 0) acc = K.accum[sumPix];
         }
     }
+    // currentIor entering this pixel's next sample, held by the pixel's summing lane and fetched by its path lanes
+    float iorPix = (GLASS && sumInside && K.sampleBase != 0) ? K.ior[sumPix] : 1.0f;
+    const int pixLane = spp >= 64 ? 0 : myPixInWave;         // the summing lane of this path lane's pixel
+    const unsigned long long segMask =                       // the lanes holding samples of this lane's pixel
+        spp >= 64 ? ~0ull : (((1ull << spp) - 1ull) << (myPixInWave * spp));
     // spp >= 64: the wave's single pixel, summed per channel by lanes 0..2 (lane 3 keeps the sample count)
     const bool sumInside0 = __shfl((int)sumInside, 0) != 0;
     const size_t sumPix0 = ((size_t)(unsigned)__shfl((int)(sumPix >> 32), 0) << 32) | (unsigned)__shfl((int)(unsigned)sumPix, 0);
@@ -206,26 +226,61 @@ __global__ __launch_bounds__(64, RZ_SAMPLES_MIN_WAVES) void rz_render_samples(co
         P.mode = MODE_DONE;
         P.addLight = mk3(0.0f, 0.0f, 0.0f);
         P.addSky = mk3(0.0f, 0.0f, 0.0f);
-        if (inside && s < spp) {
-            P.color = mk3(0.0f, 0.0f, 0.0f);
-            P.ior = 1.0f;
-            P.samp = K.sampleBase + s;
-            begin_sample<COUNT>(K, P, c);
+        P.usedIor = 0;
+        P.ior = 1.0f;
+        bool todo = inside && s < spp;               // this lane's sample still has to be (re)computed
+        float assumed = GLASS ? __shfl(iorPix, pixLane) : 1.0f;
+        Tally att = {};
+        for (;;) {
+            if (COUNT) att = Tally{};
+            if (todo) {
+                P.color = mk3(0.0f, 0.0f, 0.0f);
+                P.ior = assumed;
+                P.samp = K.sampleBase + s;
+                begin_sample<COUNT>(K, P, COUNT ? att : c);
+            }
+            while (P.mode != MODE_DONE) {
+#ifdef RZ_PROF
+                RZ_SITE(c, 6);
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+                HitRec h;
+                const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, COUNT ? att : c);
+#ifdef RZ_PROF
+                const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
+                advance<COUNT, GLASS>(K, P, found, h, COUNT ? att : c);
+#ifdef RZ_PROF
+                tTrace += t2 - t1; tAdv += __builtin_amdgcn_s_memtime() - t2;
+#endif
+            }
+            if (!GLASS) { if (COUNT && todo) tally_add(c, att); break; }
+            // ---- validate the speculation, in sample order, per pixel.  The lanes still `todo` of a pixel are a
+            // suffix of its samples and all assumed the same incoming value `assumed`.
+            //   U : samples that read currentIor;  Cm : those that also left a different value behind.
+            // Up to and including the first changer `ch` everything is right.  After it currentIor is P.ior[ch]:
+            // samples that never read it are still right, the first later reader `firstBad` (and everything after
+            // it, whose input depends on it) must be redone with the corrected value.
+            const unsigned long long U = __ballot(todo && P.usedIor) & segMask;
+            const unsigned long long Cm = __ballot(todo && P.usedIor && P.ior != assumed) & segMask;
+            int firstBad = 64;
+            float corrected = assumed;
+            if (Cm != 0ull) {
+                const int ch = __ffsll((long long)Cm) - 1;
+                corrected = __shfl(P.ior, ch);
+                const unsigned long long later = ch >= 63 ? 0ull : (U & ~((2ull << ch) - 1ull));
+                if (later != 0ull) firstBad = __ffsll((long long)later) - 1;
+            }
+            const bool redo = todo && lane >= firstBad;
+            if (COUNT && todo && !redo) tally_add(c, att);
+            todo = redo;
+            assumed = corrected;         // identical in every lane of the pixel: its currentIor after the final samples
+            if (__ballot(todo) == 0ull) break;
         }
-        while (P.mode != MODE_DONE) {
-#ifdef RZ_PROF
-            RZ_SITE(c, 6);
-            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-#endif
-            HitRec h;
-            const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, c);
-#ifdef RZ_PROF
-            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-#endif
-            advance<COUNT, false>(K, P, found, h, c);
-#ifdef RZ_PROF
-            tTrace += t2 - t1; tAdv += __builtin_amdgcn_s_memtime() - t2;
-#endif
+        if (GLASS) {                     // hand the pixel's currentIor to its summing lane (next batch / next frame)
+            const int src = spp >= 64 ? 0 : min(lane * spp, 63);
+            const float v = __shfl(assumed, src);
+            if (lane < pixPerWave) iorPix = v;
         }
         // park the addends (zeros for idle lanes: adding +0 is exact), then replay the adds in sample order
         addL[lane] = make_float4(P.addLight.x, P.addLight.y, P.addLight.z, 0.0f);
@@ -259,15 +314,15 @@ __global__ __launch_bounds__(64, RZ_SAMPLES_MIN_WAVES) void rz_render_samples(co
         __syncthreads();
     }
     if (spp >= 64) {
-        if (sumInside0) {
-            float* out = reinterpret_cast<float*>(&K.accum[sumPix0]);
-            if (lane < 3) out[lane] = chan;
-            else if (lane == 3) { out[3] = alpha0 + (float)spp; K.ior[sumPix0] = 1.0f; }
+        const float cx = __shfl(chan, 0), cy = __shfl(chan, 1), cz = __shfl(chan, 2);
+        if (sumInside0 && lane == 0) {          // one whole 16-B pixel store
+            K.accum[sumPix0] = make_float4(cx, cy, cz, alpha0 + (float)spp);
+            K.ior[sumPix0] = iorPix;
         }
     } else if (sumInside) {
         acc.w += (float)spp;
         K.accum[sumPix] = acc;
-        K.ior[sumPix] = 1.0f;
+        K.ior[sumPix] = iorPix;
     }
 #ifdef RZ_PROF
     if (COUNT) {
@@ -341,16 +396,20 @@ void dump_wave_log(int nWaves) {
 }
 #endif
 
-void launch_render_samples(const KParams& K, bool counted, hipStream_t stream) {
+void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream_t stream) {
     const int pixPerWave = K.spp >= 64 ? 1 : 64 / K.spp;
     const long long blocks = ((long long)K.nSlots + pixPerWave - 1) / pixPerWave;
     if (blocks <= 0) return;
     const size_t lds = (size_t)K.blasStackCap * 64 * sizeof(uint2) + (size_t)K.tlasStackCap * 64 * sizeof(int) +
                        2 * 64 * sizeof(float4);
-    if (counted)
-        hipLaunchKernelGGL(rz_render_samples<true>, dim3((unsigned)blocks), dim3(64), lds, stream, K);
-    else
-        hipLaunchKernelGGL(rz_render_samples<false>, dim3((unsigned)blocks), dim3(64), lds, stream, K);
+    const dim3 g((unsigned)blocks), b(64);
+    if (glass) {
+        if (counted) hipLaunchKernelGGL((rz_render_samples<true, true>), g, b, lds, stream, K);
+        else hipLaunchKernelGGL((rz_render_samples<false, true>), g, b, lds, stream, K);
+    } else {
+        if (counted) hipLaunchKernelGGL((rz_render_samples<true, false>), g, b, lds, stream, K);
+        else hipLaunchKernelGGL((rz_render_samples<false, false>), g, b, lds, stream, K);
+    }
 }
 
 void launch_resolve(const float4* accum, uchar4* out, int n, hipStream_t stream) {

@@ -44,6 +44,7 @@ struct Path {
     // The one-lane-per-pixel kernel adds them to `color` on the spot and never reads these; the
     // one-lane-per-sample kernel stores them and rz_sum_samples replays the adds in order.
     v3 addLight, addSky;
+    int usedIor;        // this sample read (and possibly changed) currentIor: FS:727-742 executed
 };
 
 // FS:204-212 + FS:688-692
@@ -68,6 +69,7 @@ __device__ __forceinline__ void begin_sample(const KParams& K, Path& P, Tally& c
     P.mode = MODE_SEGMENT;
     P.addLight = mk3(0.0f, 0.0f, 0.0f);
     P.addSky = mk3(0.0f, 0.0f, 0.0f);
+    P.usedIor = 0;
 }
 
 __device__ __forceinline__ void end_sample(Path& P) {
@@ -203,6 +205,7 @@ __device__ __forceinline__ void scatter(const KParams& K, Path& P) {
     const v3 hitNormal = P.hn;
     v3 dir = P.pdir;
     if (GLASS && M.transparency > 0.0f) {
+        P.usedIor = 1;
         const bool entering = dot(-dir, hitNormal) > 0.0f;
         const v3 N = entering ? hitNormal : -hitNormal;
         const float extIor = P.ior;
