@@ -223,21 +223,17 @@ __global__ __launch_bounds__(64, RZ_SAMPLES_MIN_WAVES) void rz_render_samples(co
 #endif
     for (int b = 0; b < nBatches; ++b) {
         const int s = spp >= 64 ? b * 64 + lane : lane - myPixInWave * spp;
+        const bool mine = inside && s < spp;          // this lane has a sample in this batch
         P.mode = MODE_DONE;
         P.addLight = mk3(0.0f, 0.0f, 0.0f);
         P.addSky = mk3(0.0f, 0.0f, 0.0f);
         P.usedIor = 0;
         P.ior = 1.0f;
-        bool todo = inside && s < spp;               // this lane's sample still has to be (re)computed
-        float assumed = GLASS ? __shfl(iorPix, pixLane) : 1.0f;
-        Tally att = {};
-        for (;;) {
-            if (COUNT) att = Tally{};
-            if (todo) {
+        if constexpr (!GLASS) {
+            if (mine) {
                 P.color = mk3(0.0f, 0.0f, 0.0f);
-                P.ior = assumed;
                 P.samp = K.sampleBase + s;
-                begin_sample<COUNT>(K, P, COUNT ? att : c);
+                begin_sample<COUNT>(K, P, c);
             }
             while (P.mode != MODE_DONE) {
 #ifdef RZ_PROF
@@ -245,79 +241,128 @@ __global__ __launch_bounds__(64, RZ_SAMPLES_MIN_WAVES) void rz_render_samples(co
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
                 HitRec h;
-                const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, COUNT ? att : c);
+                const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, c);
 #ifdef RZ_PROF
                 const unsigned long long t2 = __builtin_amdgcn_s_memtime();
 #endif
-                advance<COUNT, GLASS>(K, P, found, h, COUNT ? att : c);
+                advance<COUNT, false>(K, P, found, h, c);
 #ifdef RZ_PROF
                 tTrace += t2 - t1; tAdv += __builtin_amdgcn_s_memtime() - t2;
 #endif
             }
-            if (!GLASS) { if (COUNT && todo) tally_add(c, att); break; }
-            // ---- validate the speculation, in sample order, per pixel.  The lanes still `todo` of a pixel are a
-            // suffix of its samples and all assumed the same incoming value `assumed`.
-            //   U : samples that read currentIor;  Cm : those that also left a different value behind.
-            // Up to and including the first changer `ch` everything is right.  After it currentIor is P.ior[ch]:
-            // samples that never read it are still right, the first later reader `firstBad` (and everything after
-            // it, whose input depends on it) must be redone with the corrected value.
-            const unsigned long long U = __ballot(todo && P.usedIor) & segMask;
-            const unsigned long long Cm = __ballot(todo && P.usedIor && P.ior != assumed) & segMask;
-            int firstBad = 64;
-            float corrected = assumed;
-            if (Cm != 0ull) {
-                const int ch = __ffsll((long long)Cm) - 1;
-                corrected = __shfl(P.ior, ch);
-                const unsigned long long later = ch >= 63 ? 0ull : (U & ~((2ull << ch) - 1ull));
-                if (later != 0ull) firstBad = __ffsll((long long)later) - 1;
-            }
-            const bool redo = todo && lane >= firstBad;
-            if (COUNT && todo && !redo) tally_add(c, att);
-            todo = redo;
-            assumed = corrected;         // identical in every lane of the pixel: its currentIor after the final samples
-            if (__ballot(todo) == 0ull) break;
-        }
-        if (GLASS) {                     // hand the pixel's currentIor to its summing lane (next batch / next frame)
-            const int src = spp >= 64 ? 0 : min(lane * spp, 63);
-            const float v = __shfl(assumed, src);
-            if (lane < pixPerWave) iorPix = v;
-        }
-        // park the addends (zeros for idle lanes: adding +0 is exact), then replay the adds in sample order
-        addL[lane] = make_float4(P.addLight.x, P.addLight.y, P.addLight.z, 0.0f);
-        addS[lane] = make_float4(P.addSky.x, P.addSky.y, P.addSky.z, 0.0f);
-        __syncthreads();
-        if (spp >= 64) {
-            // one pixel per wave: the three colour channels are independent chains -> lanes 0,1,2 take one each
-            // (a 128-add dependent chain per batch instead of 384 on one lane)
-            if (lane < 3 && sumInside0) {
-                const float* Lf = reinterpret_cast<const float*>(addL) + lane;
-                const float* Sf = reinterpret_cast<const float*>(addS) + lane;
-                const int n = min(64, spp - b * 64);
-                int k = 0;
-                for (; k + 8 <= n; k += 8) {
-                    float l[8], q[8];
+            // park the addends (zeros for idle lanes: adding +0 is exact), then replay the adds in sample order
+            addL[lane] = make_float4(P.addLight.x, P.addLight.y, P.addLight.z, 0.0f);
+            addS[lane] = make_float4(P.addSky.x, P.addSky.y, P.addSky.z, 0.0f);
+            __syncthreads();
+            if (spp >= 64) {
+                // one pixel per wave: the three colour channels are independent chains -> lanes 0,1,2 take one each
+                // (a 128-add dependent chain per batch instead of 384 on one lane)
+                if (lane < 3 && sumInside0) {
+                    const float* Lf = reinterpret_cast<const float*>(addL) + lane;
+                    const float* Sf = reinterpret_cast<const float*>(addS) + lane;
+                    const int n = min(64, spp - b * 64);
+                    int k = 0;
+                    for (; k + 8 <= n; k += 8) {
+                        float l[8], q[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { l[u] = Lf[4 * (k + u)]; q[u] = Sf[4 * (k + u)]; }
+                        for (int u = 0; u < 8; ++u) { l[u] = Lf[4 * (k + u)]; q[u] = Sf[4 * (k + u)]; }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { chan = chan + l[u]; chan = chan + q[u]; }   // FS:717, FS:709
+                        for (int u = 0; u < 8; ++u) { chan = chan + l[u]; chan = chan + q[u]; }   // FS:717, FS:709
+                    }
+                    for (; k < n; ++k) { chan = chan + Lf[4 * k]; chan = chan + Sf[4 * k]; }
                 }
-                for (; k < n; ++k) { chan = chan + Lf[4 * k]; chan = chan + Sf[4 * k]; }
+            } else if (sumInside) {
+                const int first = lane * spp;
+                for (int k = 0; k < spp; ++k) {
+                    const float4 L = addL[first + k], S = addS[first + k];
+                    acc.x = acc.x + L.x; acc.y = acc.y + L.y; acc.z = acc.z + L.z;     // FS:717
+                    acc.x = acc.x + S.x; acc.y = acc.y + S.y; acc.z = acc.z + S.z;     // FS:709
+                }
             }
-        } else if (sumInside) {
-            const int first = lane * spp;
-            for (int k = 0; k < spp; ++k) {
-                const float4 L = addL[first + k], S = addS[first + k];
-                acc.x = acc.x + L.x; acc.y = acc.y + L.y; acc.z = acc.z + L.z;     // FS:717
-                acc.x = acc.x + S.x; acc.y = acc.y + S.y; acc.z = acc.z + S.z;     // FS:709
+            __syncthreads();
+        } else {
+            // ---- transparent scenes: memoised speculation on currentIor (FS:674).
+            // A sample's result depends on the currentIor it starts from only if it scatters at a transparent surface
+            // (usedIor).  Each lane keeps up to two VERSIONS of its sample in LDS, keyed by the incoming value it was
+            // computed from.  The pixel's summing lane consumes samples in order, taking for each the version whose key
+            // equals the currentIor left by the previous one (any version will do if the sample never read it), and
+            // stops at the first sample that lacks the version it needs; exactly the lanes that lack the wanted
+            // version are then (re)run.  currentIor only ever takes the values 1.0 and the ior of a transparent
+            // material, so with one glass material every sample is computed at most twice.
+            float4* verL = addL;                                  // [2][64]: addend FS:717, .w = incoming ior (key)
+            float4* verS = addL + 128;                            // [2][64]: addend FS:709, .w = outgoing ior
+            int* vinfo = reinterpret_cast<int*>(addL + 256);      // [2][64]: bit0 valid, bit1 usedIor
+            int* chosen = vinfo + 128;                            // [64]: version the summing lane consumed
+            vinfo[lane] = 0; vinfo[64 + lane] = 0;
+            float keyv[2] = {0.0f, 0.0f};
+            int infov[2] = {0, 0};
+            int nextSlot = 0;
+            int consumed = 0;                                     // summing lanes: samples of my pixel already added
+            const int nMine = spp >= 64 ? min(64, spp - b * 64) : spp;
+            const int firstLane = spp >= 64 ? 0 : lane * spp;     // summing lanes: first lane of my pixel
+            Tally tv[2] = {};
+            __syncthreads();
+            for (;;) {
+                const int cons = __shfl(consumed, pixLane);
+                const float want = __shfl(iorPix, pixLane);
+                const int sIdx = spp >= 64 ? lane : s;            // index of my sample within its pixel's batch
+                bool have = false;
+#pragma unroll
+                for (int v = 0; v < 2; ++v) have = have || ((infov[v] & 1) && (!(infov[v] & 2) || keyv[v] == want));
+                const bool run = mine && sIdx >= cons && !have;
+                Tally att = {};
+                if (run) {
+                    P.color = mk3(0.0f, 0.0f, 0.0f);
+                    P.ior = want;
+                    P.samp = K.sampleBase + s;
+                    begin_sample<COUNT>(K, P, COUNT ? att : c);
+                }
+                while (P.mode != MODE_DONE) {
+                    HitRec h;
+                    const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, COUNT ? att : c);
+                    advance<COUNT, true>(K, P, found, h, COUNT ? att : c);
+                }
+                if (run) {
+                    const int slot = nextSlot;
+                    nextSlot ^= 1;
+                    keyv[slot] = want;
+                    infov[slot] = 1 | (P.usedIor ? 2 : 0);
+                    verL[slot * 64 + lane] = make_float4(P.addLight.x, P.addLight.y, P.addLight.z, want);
+                    verS[slot * 64 + lane] = make_float4(P.addSky.x, P.addSky.y, P.addSky.z, P.ior);
+                    vinfo[slot * 64 + lane] = infov[slot];
+                    if (COUNT) tv[slot] = att;
+                }
+                __syncthreads();
+                if (sumInside) {
+                    while (consumed < nMine) {
+                        const int k = firstLane + consumed;
+                        int pick = -1;
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+                            const int inf = vinfo[v * 64 + k];
+                            if (pick < 0 && (inf & 1) && (!(inf & 2) || verL[v * 64 + k].w == iorPix)) pick = v;
+                        }
+                        if (pick < 0) break;
+                        const float4 L = verL[pick * 64 + k], S = verS[pick * 64 + k];
+                        acc.x = acc.x + L.x; acc.y = acc.y + L.y; acc.z = acc.z + L.z;     // FS:717
+                        acc.x = acc.x + S.x; acc.y = acc.y + S.y; acc.z = acc.z + S.z;     // FS:709
+                        if (vinfo[pick * 64 + k] & 2) iorPix = S.w;                        // FS:742
+                        chosen[k] = pick;
+                        ++consumed;
+                    }
+                }
+                __syncthreads();
+                if (__ballot(sumInside && consumed < nMine) == 0ull) break;
             }
+            if (COUNT && mine) tally_add(c, tv[chosen[lane]]);
+            __syncthreads();
         }
-        __syncthreads();
     }
-    if (spp >= 64) {
+    if (!GLASS && spp >= 64) {
         const float cx = __shfl(chan, 0), cy = __shfl(chan, 1), cz = __shfl(chan, 2);
         if (sumInside0 && lane == 0) {          // one whole 16-B pixel store
             K.accum[sumPix0] = make_float4(cx, cy, cz, alpha0 + (float)spp);
-            K.ior[sumPix0] = iorPix;
+            K.ior[sumPix0] = 1.0f;
         }
     } else if (sumInside) {
         acc.w += (float)spp;
@@ -400,8 +445,9 @@ void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream
     const int pixPerWave = K.spp >= 64 ? 1 : 64 / K.spp;
     const long long blocks = ((long long)K.nSlots + pixPerWave - 1) / pixPerWave;
     if (blocks <= 0) return;
+    // after the stacks: 2 x 64 float4 of addends; the speculating variant keeps two versions + bookkeeping
     const size_t lds = (size_t)K.blasStackCap * 64 * sizeof(uint2) + (size_t)K.tlasStackCap * 64 * sizeof(int) +
-                       2 * 64 * sizeof(float4);
+                       (glass ? 4 * 64 * sizeof(float4) + 3 * 64 * sizeof(int) : 2 * 64 * sizeof(float4));
     const dim3 g((unsigned)blocks), b(64);
     if (glass) {
         if (counted) hipLaunchKernelGGL((rz_render_samples<true, true>), g, b, lds, stream, K);
