@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Side harness: the BASELINE.json configurations other than the headline one, on ONE GPU.
+
+  c1  Cornell (16 tris) 256x256, 4 spp, 1 bounce
+  c4  16 instances of the bunny mesh (one shared BLAS), 1080p, 16 spp, 4 bounces, 30 frames; per frame the host
+      re-derives the transforms, rebuilds the TLAS (librayzen_host) and rz_update()s instances + TLAS -- all inside
+      the timed region, as RayZen's frame loop does (main.cpp:572)
+  c5  ~1M-triangle mesh, 3840x2160, 128 spp, 8 bounces (the per-GPU share of the 8-GPU config is 1/8 of the pixels;
+      here one GPU renders the whole frame)
+bench.py stays the driver-facing benchmark (configs[1]); this prints one JSON line per config.
+"""
+import json
+import sys
+import time
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+
+
+def main():
+    which = sys.argv[1:] or ["c1", "c4", "c5"]
+    from rayzen_amd import scene as S
+    from rayzen_amd.renderer import Renderer, algorithmic_bytes, frame_params
+    for name in which:
+        t_build = time.perf_counter()
+        if name == "c1":
+            sc, W, H, spp, b, frames = S.cornell_scene(), 256, 256, 4, 1, 20
+        elif name == "c4":
+            sc, W, H, spp, b, frames = S.instanced_scene(n=76, count=16, aspect=1920 / 1080), 1920, 1080, 16, 4, 30
+        elif name == "c5":
+            sc, W, H, spp, b, frames = S.stress_scene(n=289, aspect=3840 / 2160), 3840, 2160, 128, 8, 3
+        else:
+            raise SystemExit(name)
+        t_build = time.perf_counter() - t_build
+        r = Renderer(0)
+        t_up = time.perf_counter()
+        r.upload_scene(sc)
+        r.set_frame(frame_params(sc.camera, W, H, len(sc.lights), b, spp))
+        r.render(); r.sync()                                   # includes the one-time re-layout
+        t_up = time.perf_counter() - t_up
+        cnt = r.render_counted()
+        r.render_history_ms()
+        t0 = time.perf_counter()
+        for f in range(frames):
+            if name == "c4":
+                for oid, t in zip(sc.instance_ids, S.instanced_transforms(f + 1, 16)):
+                    sc.set_transform(oid, t)
+                sc.update_dynamic()
+                r.update_dynamic(sc)
+            r.render()
+        r.sync()
+        dt = time.perf_counter() - t0
+        kms = r.render_history_ms()
+        out = {"config": name, "scene": sc.name, "triangles": int(sc.arrays[S.BIND_TRIANGLES].shape[0]),
+               "instances": int(sc.arrays[S.BIND_INSTANCES].shape[0]), "blas_depth": sc.max_blas_depth,
+               "width": W, "height": H, "spp": spp, "bounces": b, "frames": frames,
+               "ms_per_frame_wall": round(dt / frames * 1e3, 3), "kernel_ms": round(sum(kms) / len(kms), 3),
+               "msamples_per_s": round(W * H * spp * frames / dt / 1e6, 1), "kernel": r.last_kernel_name(),
+               "algorithmic_bytes_per_sample": round(algorithmic_bytes(cnt) / cnt["samples"], 1),
+               "host_scene_build_s": round(t_build, 3), "upload_relayout_first_frame_s": round(t_up, 3)}
+        print(json.dumps(out), flush=True)
+        r.close()
+
+
+if __name__ == "__main__":
+    main()

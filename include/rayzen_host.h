@@ -51,6 +51,12 @@ int  rzh_scene_update_dynamic(rzh_scene* s);
  * the next build/update/destroy */
 const void* rzh_scene_buffer(const rzh_scene* s, rz_binding b, size_t* bytes);
 void rzh_scene_depths(const rzh_scene* s, int* max_blas_depth, int* tlas_depth);
+/* RayZen's SSBO disk cache (src/main.cpp:94-115, 914-939, 1037-1043): six files `ssbo_v2_{triangles,blasnodes,
+ * blastris,instances,tlasnodes,tlastris}.bin` in `dir`, each a native size_t count + raw POD array.  save: after
+ * rzh_scene_build; load: replaces the scene's arrays (rzh_scene_update_dynamic then needs objects added in the same
+ * order as the cached instances).  0 on success, -1 on any I/O or consistency failure. */
+int rzh_scene_save_cache(const rzh_scene* s, const char* dir);
+int rzh_scene_load_cache(rzh_scene* s, const char* dir);
 
 /* Camera (include/Camera.h:42-48) + the inverses sendSceneDataToShader
  * uploads (src/main.cpp:1363-1364).  target is a direction. All column-major. */

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "RayZenScene.h"
+#include "SceneCache.h"
 
 using namespace rayzen;
 
@@ -121,6 +122,18 @@ const void* rzh_scene_buffer(const rzh_scene* s, rz_binding b, size_t* bytes) {
     }
     if (bytes) *bytes = n;
     return p;
+}
+
+int rzh_scene_save_cache(const rzh_scene* s, const char* dir) {
+    if (!s || !s->built || !dir) return -1;
+    return saveSceneCache(dir, s->buffers) ? 0 : -1;
+}
+
+int rzh_scene_load_cache(rzh_scene* s, const char* dir) {
+    if (!s || !dir) return -1;
+    if (!loadSceneCache(dir, s->buffers)) return -1;
+    s->built = true;
+    return 0;
 }
 
 void rzh_scene_depths(const rzh_scene* s, int* max_blas_depth, int* tlas_depth) {

@@ -239,6 +239,21 @@ class Scene:
         self._pull(GEOMETRY_BINDINGS)
         return self
 
+    def save_cache(self, directory):
+        """Write RayZen's ssbo_v2_*.bin cache files (main.cpp:1037-1043)."""
+        import os
+        os.makedirs(directory, exist_ok=True)
+        if _lib.host().rzh_scene_save_cache(self._h, os.fsencode(directory)) != 0:
+            raise OSError(f"cannot write the scene cache to {directory}")
+
+    def load_cache(self, directory):
+        """Read RayZen's ssbo_v2_*.bin cache files (main.cpp:914-939) in place of build()."""
+        import os
+        if _lib.host().rzh_scene_load_cache(self._h, os.fsencode(directory)) != 0:
+            raise OSError(f"no usable scene cache in {directory}")
+        self._pull(GEOMETRY_BINDINGS)
+        return self
+
     def update_dynamic(self):
         if _lib.host().rzh_scene_update_dynamic(self._h) != 0:
             raise RuntimeError("rzh_scene_update_dynamic failed")

@@ -118,3 +118,28 @@ def test_camera_matrices_are_consistent():
     assert np.allclose((V @ np.array([1, 2, 3, 1.0]))[:3], 0, atol=1e-5)             # eye maps to the origin
     f = 1.0 / np.tan(np.radians(70.0) / 2)
     assert abs(P[1, 1] - f) < 1e-5 and abs(P[0, 0] - f / (16 / 9)) < 1e-5 and P[3, 2] == -1.0
+
+
+def test_scene_cache_round_trip_in_rayzen_format(tmp_path):
+    """main.cpp:94-115: every cache file is a native size_t count followed by the raw POD array."""
+    import struct
+    sc = S.bunny_scene(n=5, extras=True)
+    d = str(tmp_path / "bvh_cache" / "v2")
+    sc.save_cache(d)
+    names = {"triangles": S.BIND_TRIANGLES, "blasnodes": S.BIND_BLAS_NODES, "blastris": S.BIND_BLAS_INDICES,
+             "instances": S.BIND_INSTANCES, "tlasnodes": S.BIND_TLAS_NODES, "tlastris": S.BIND_TLAS_INDICES}
+    for name, b in names.items():
+        raw = open(os.path.join(d, f"ssbo_v2_{name}.bin"), "rb").read()
+        (n,) = struct.unpack("<Q", raw[:8])
+        assert n == len(sc.arrays[b]) and raw[8:] == sc.arrays[b].tobytes()
+    other = S.Scene().load_cache(d)
+    for b in names.values():
+        assert other.arrays[b].tobytes() == sc.arrays[b].tobytes()
+    assert (other.max_blas_depth, other.tlas_depth) == (sc.max_blas_depth, sc.tlas_depth)
+    # a truncated file is refused, not trusted
+    p = os.path.join(d, "ssbo_v2_blasnodes.bin")
+    raw = open(p, "rb").read()
+    open(p, "wb").write(raw[:len(raw) // 2])
+    import pytest
+    with pytest.raises(OSError):
+        S.Scene().load_cache(d)
