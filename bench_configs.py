@@ -5,6 +5,7 @@
   c4  16 instances of the bunny mesh (one shared BLAS), 1080p, 16 spp, 4 bounces, 30 frames; per frame the host
       re-derives the transforms, rebuilds the TLAS (librayzen_host) and rz_update()s instances + TLAS -- all inside
       the timed region, as RayZen's frame loop does (main.cpp:572)
+  c4d the same frames with rz_update_transforms: inverse, world AABBs and the TLAS rebuild run on the GPU
   c5  ~1M-triangle mesh, 3840x2160, 128 spp, 8 bounces (the per-GPU share of the 8-GPU config is 1/8 of the pixels;
       here one GPU renders the whole frame)
 bench.py stays the driver-facing benchmark (configs[1]); this prints one JSON line per config.
@@ -17,14 +18,14 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(_
 
 
 def main():
-    which = sys.argv[1:] or ["c1", "c4", "c5"]
+    which = sys.argv[1:] or ["c1", "c4", "c4d", "c5"]
     from rayzen_amd import scene as S
     from rayzen_amd.renderer import Renderer, algorithmic_bytes, frame_params
     for name in which:
         t_build = time.perf_counter()
         if name == "c1":
             sc, W, H, spp, b, frames = S.cornell_scene(), 256, 256, 4, 1, 20
-        elif name == "c4":
+        elif name in ("c4", "c4d"):
             sc, W, H, spp, b, frames = S.instanced_scene(n=76, count=16, aspect=1920 / 1080), 1920, 1080, 16, 4, 30
         elif name == "c5":
             sc, W, H, spp, b, frames = S.stress_scene(n=289, aspect=3840 / 2160), 3840, 2160, 128, 8, 3
@@ -32,6 +33,7 @@ def main():
             raise SystemExit(name)
         t_build = time.perf_counter() - t_build
         r = Renderer(0)
+        floor_xf = sc.arrays[S.BIND_INSTANCES]["transform"][0].copy() if name == "c4d" else None
         t_up = time.perf_counter()
         r.upload_scene(sc)
         r.set_frame(frame_params(sc.camera, W, H, len(sc.lights), b, spp))
@@ -41,11 +43,14 @@ def main():
         r.render_history_ms()
         t0 = time.perf_counter()
         for f in range(frames):
-            if name == "c4":
+            if name == "c4":            # host TLAS rebuild + glBufferSubData-style update
                 for oid, t in zip(sc.instance_ids, S.instanced_transforms(f + 1, 16)):
                     sc.set_transform(oid, t)
                 sc.update_dynamic()
                 r.update_dynamic(sc)
+            elif name == "c4d":         # device-side rebuild: only the transforms cross the bus
+                import numpy as np
+                r.update_transforms(np.stack([floor_xf] + S.instanced_transforms(f + 1, 16)))
             r.render()
         r.sync()
         dt = time.perf_counter() - t0

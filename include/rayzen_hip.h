@@ -167,6 +167,17 @@ int rz_upload(rz_ctx* ctx, rz_binding binding, const void* data, size_t bytes);
 int rz_update(rz_ctx* ctx, rz_binding binding, size_t offset,
               const void* data, size_t bytes);
 
+/* updateDynamicBVHAndSSBOs (main.cpp:1138-1194) done ON THE DEVICE: hand over only the per-instance transforms
+ * (n x 16 floats, column-major, n == number of uploaded instances); the library inverts them, recomputes the world
+ * AABBs (main.cpp:1168-1191) and rebuilds the TLAS (BVH.cpp:178-240) in one small kernel.  The result is byte-identical
+ * to what RayZen's CPU code would upload with glBufferSubData; rz_read_binding returns it.  Synchronises the context's
+ * stream (the TLAS depth sizes the next launch). */
+int rz_update_transforms(rz_ctx* ctx, const float* transforms, size_t n);
+
+/* Copy a binding's current content back to the host in RayZen's own layout (after rz_update_transforms: the
+ * instances / TLAS nodes / TLAS indices the device built).  out == NULL: only *needed is set. */
+int rz_read_binding(rz_ctx* ctx, rz_binding binding, void* out, size_t bytes, size_t* needed);
+
 /* glUniform* in sendSceneDataToShader (main.cpp:1356-1379). */
 int rz_set_frame(rz_ctx* ctx, const rz_frame_params* params);
 

@@ -25,6 +25,11 @@
 #include "rz_wavefront.h"
 
 namespace rz {
+struct TlasWork {       // rz_tlas_device.hip
+    const float* transforms; DevInstance* instances; rz_bvh_instance* refInstances; TlasNode* nodes; int32_t* indices;
+    float* worldMin; float* worldMax; int32_t* order; int32_t* stack; int32_t* outCounts; int n;
+};
+void launch_tlas_refit(const TlasWork& W, hipStream_t s);
 #ifdef RZ_PROF
 void dump_wave_log(int nWaves);
 #endif
@@ -106,6 +111,11 @@ struct rz_ctx {
     DevBuf ownAccum, dIor;
     // queued pipeline (rz_wavefront.hip)
     DevBuf wfState, wfQueues, wfCounts;
+    // device-side dynamic update (rz_update_transforms)
+    DevBuf dXforms, dInstRef, dTlasScratch;
+    int* tlasHostCounts = nullptr;      // pinned: node count, index count, depth
+    bool deviceOwnsTlas = false;        // instances + TLAS on the device are newer than the host copies
+    int devTlasNodes = 0;
     bool sceneHasTransparency = true;   // some triangle uses a material with transparency > 0
     int wfSlots = 0;
     int wfTraceBlocks = 0;
@@ -236,6 +246,22 @@ int build_view(rz_ctx* c, int nodeOff, int triOff, int gTriOff, BlasView& V) {
         d.src = (int32_t)src;
         c->hTris.push_back(d);
     }
+    return RZ_OK;
+}
+
+// After rz_update_transforms the device holds newer instances / TLAS than the host copies: bring them back
+// (3.4 KB at 16 instances) before anything reads or patches those copies.
+int sync_host_from_device(rz_ctx* c) {
+    if (!c->deviceOwnsTlas) return RZ_OK;
+    const size_t nInst = hostCount<rz_bvh_instance>(c, RZ_BIND_INSTANCES);
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    const int nn = c->tlasHostCounts[0], ni = c->tlasHostCounts[1];
+    c->host[RZ_BIND_TLAS_NODES].resize((size_t)nn * sizeof(rz_bvh_node));
+    c->host[RZ_BIND_TLAS_INDICES].resize((size_t)ni * sizeof(int32_t));
+    if (nInst) RZ_HIP(c, hipMemcpy(c->host[RZ_BIND_INSTANCES].data(), c->dInstRef.p, nInst * sizeof(rz_bvh_instance), hipMemcpyDeviceToHost));
+    if (nn) RZ_HIP(c, hipMemcpy(c->host[RZ_BIND_TLAS_NODES].data(), c->dTlasNodes.p, (size_t)nn * sizeof(rz_bvh_node), hipMemcpyDeviceToHost));
+    if (ni) RZ_HIP(c, hipMemcpy(c->host[RZ_BIND_TLAS_INDICES].data(), c->dTlasIdx.p, (size_t)ni * sizeof(int32_t), hipMemcpyDeviceToHost));
+    c->deviceOwnsTlas = false;
     return RZ_OK;
 }
 
@@ -468,7 +494,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     K.lights = static_cast<const DevLight*>(c->dLight.p);
     K.accum = accum;
     K.ior = static_cast<float*>(c->dIor.p);
-    K.nTlasNodes = (int)hostCount<rz_bvh_node>(c, RZ_BIND_TLAS_NODES);
+    K.nTlasNodes = c->deviceOwnsTlas ? c->devTlasNodes : (int)hostCount<rz_bvh_node>(c, RZ_BIND_TLAS_NODES);
     K.nLights = std::max(0, std::min<int>(f.num_lights, (int)hostCount<rz_light>(c, RZ_BIND_LIGHTS)));
     K.nMaterials = (int)hostCount<rz_material>(c, RZ_BIND_MATERIALS);
     K.width = f.width; K.height = f.height;
@@ -590,9 +616,10 @@ void rz_destroy(rz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
-                      &c->dCounters, &c->dResolve, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts})
+                      &c->dCounters, &c->dResolve, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts, &c->dXforms, &c->dInstRef, &c->dTlasScratch})
         b->release();
     if (c->wfHostCount) (void)hipHostFree(c->wfHostCount);
+    if (c->tlasHostCounts) (void)hipHostFree(c->tlasHostCounts);
     for (int i = 0; i < rz_ctx::kRing; ++i) {
         if (c->evStart[i]) (void)hipEventDestroy(c->evStart[i]);
         if (c->evStop[i]) (void)hipEventDestroy(c->evStop[i]);
@@ -607,6 +634,7 @@ int rz_upload(rz_ctx* c, rz_binding binding, const void* data, size_t bytes) {
     if (es == 0) return fail(c, RZ_ERR_INVALID_ARG, "unknown binding %d", (int)binding);
     if (bytes % es) return fail(c, RZ_ERR_INVALID_ARG, "binding %d: %zu bytes is not a multiple of the %zu-byte element", (int)binding, bytes, es);
     if (bytes && !data) return fail(c, RZ_ERR_INVALID_ARG, "null data");
+    if (c->deviceOwnsTlas) { int rc = sync_host_from_device(c); if (rc != RZ_OK) return rc; }
     try {
         c->host[binding].assign(static_cast<const unsigned char*>(data), static_cast<const unsigned char*>(data) + bytes);
     } catch (...) { return fail(c, RZ_ERR_HIP, "out of host memory"); }
@@ -626,6 +654,7 @@ int rz_update(rz_ctx* c, rz_binding binding, size_t offset, const void* data, si
     if (elem_size((int)binding) == 0) return fail(c, RZ_ERR_INVALID_ARG, "unknown binding %d", (int)binding);
     if (!c->present[binding]) return fail(c, RZ_ERR_NOT_READY, "binding %d has not been uploaded", (int)binding);
     if (bytes && !data) return fail(c, RZ_ERR_INVALID_ARG, "null data");
+    if (c->deviceOwnsTlas) { int rc = sync_host_from_device(c); if (rc != RZ_OK) return rc; }
     if (offset > c->host[binding].size() || bytes > c->host[binding].size() - offset)
         return fail(c, RZ_ERR_OUT_OF_RANGE, "binding %d: update [%zu,+%zu) past its %zu bytes", (int)binding, offset, bytes, c->host[binding].size());
     if (bytes == 0) return RZ_OK;
@@ -638,6 +667,69 @@ int rz_update(rz_ctx* c, rz_binding binding, size_t offset, const void* data, si
         case RZ_BIND_INSTANCES: c->instDirty = true; break;
         default: c->geomDirty = true; break;
     }
+    return RZ_OK;
+}
+
+int rz_update_transforms(rz_ctx* c, const float* transforms, size_t n) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    if (!transforms && n) return fail(c, RZ_ERR_INVALID_ARG, "null transforms");
+    RZ_HIP(c, hipSetDevice(c->device));
+    int rc = finalize(c);           // the device scene must exist (BLAS root boxes live in DevInstance)
+    if (rc != RZ_OK) return rc;
+    const size_t nInst = hostCount<rz_bvh_instance>(c, RZ_BIND_INSTANCES);
+    if (n != nInst) return fail(c, RZ_ERR_INVALID_ARG, "%zu transforms for %zu instances", n, nInst);
+    if (n == 0) return RZ_OK;
+    if (n > (size_t)1 << 20) return fail(c, RZ_ERR_INVALID_ARG, "too many instances for the device TLAS builder");
+    if (!c->tlasHostCounts) RZ_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->tlasHostCounts), 64, hipHostMallocDefault));
+    rc = ensure(c, c->dXforms, n * 64);
+    if (rc != RZ_OK) return rc;
+    rc = ensure(c, c->dInstRef, n * sizeof(rz_bvh_instance));
+    if (rc != RZ_OK) return rc;
+    rc = ensure(c, c->dTlasNodes, (2 * n) * sizeof(rz_bvh_node));
+    if (rc != RZ_OK) return rc;
+    rc = ensure(c, c->dTlasIdx, n * sizeof(int32_t));
+    if (rc != RZ_OK) return rc;
+    // scratch: worldMin, worldMax (3n floats each), order + depth (2n+8 ints... the depth stack shares order's tail), stack 3*(2n+8), counts 16
+    const size_t stackInts = 3 * (2 * n + 8), orderInts = n + (2 * n + 8);
+    rc = ensure(c, c->dTlasScratch, (6 * n) * 4 + orderInts * 4 + stackInts * 4 + 64);
+    if (rc != RZ_OK) return rc;
+    // the reference-layout records keep their offsets: seed them from the host copy once per host-side change
+    RZ_HIP(c, hipMemcpyAsync(c->dInstRef.p, c->host[RZ_BIND_INSTANCES].data(), n * sizeof(rz_bvh_instance), hipMemcpyHostToDevice, c->stream));
+    RZ_HIP(c, hipMemcpyAsync(c->dXforms.p, transforms, n * 64, hipMemcpyHostToDevice, c->stream));
+    TlasWork W{};
+    char* sc = static_cast<char*>(c->dTlasScratch.p);
+    W.transforms = static_cast<const float*>(c->dXforms.p);
+    W.instances = static_cast<DevInstance*>(c->dInst.p);
+    W.refInstances = static_cast<rz_bvh_instance*>(c->dInstRef.p);
+    W.nodes = static_cast<TlasNode*>(c->dTlasNodes.p);
+    W.indices = static_cast<int32_t*>(c->dTlasIdx.p);
+    W.worldMin = reinterpret_cast<float*>(sc);
+    W.worldMax = W.worldMin + 3 * n;
+    W.order = reinterpret_cast<int32_t*>(W.worldMax + 3 * n);
+    W.stack = W.order + orderInts;
+    W.outCounts = W.stack + stackInts;
+    W.n = (int)n;
+    launch_tlas_refit(W, c->stream);
+    RZ_HIP(c, hipGetLastError());
+    RZ_HIP(c, hipMemcpyAsync(c->tlasHostCounts, W.outCounts, 12, hipMemcpyDeviceToHost, c->stream));
+    // the caller's transform array may die after this call returns, and the TLAS depth sizes the LDS stack
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    c->devTlasNodes = c->tlasHostCounts[0];
+    c->tlasDepth = std::max(1, c->tlasHostCounts[2]);
+    c->deviceOwnsTlas = true;
+    return RZ_OK;
+}
+
+int rz_read_binding(rz_ctx* c, rz_binding binding, void* out, size_t bytes, size_t* needed) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    if (elem_size((int)binding) == 0) return fail(c, RZ_ERR_INVALID_ARG, "unknown binding %d", (int)binding);
+    if (!c->present[binding]) return fail(c, RZ_ERR_NOT_READY, "binding %d has not been uploaded", (int)binding);
+    if (c->deviceOwnsTlas) { int rc = sync_host_from_device(c); if (rc != RZ_OK) return rc; c->deviceOwnsTlas = true; }
+    const size_t have = c->host[binding].size();
+    if (needed) *needed = have;
+    if (!out) return RZ_OK;
+    if (bytes < have) return fail(c, RZ_ERR_BUFFER_SIZE, "binding %d holds %zu bytes, buffer has %zu", (int)binding, have, bytes);
+    if (have) std::memcpy(out, c->host[binding].data(), have);
     return RZ_OK;
 }
 

@@ -45,6 +45,13 @@ public:
         upd(RZ_BIND_TLAS_NODES, buffers_.tlasNodes);
         upd(RZ_BIND_TLAS_INDICES, buffers_.tlasTriIndices);
     }
+    // The same per-frame step with the work done on the GPU: only the transforms (64 B per object) are handed over;
+    // inverse, world AABBs and the TLAS rebuild run in the library (rz_update_transforms).
+    void updateDynamicBVHAndSSBOsOnDevice(const Scene& scene) {
+        std::vector<float> xf(scene.gameObjects.size() * 16);
+        for (size_t i = 0; i < scene.gameObjects.size(); ++i) std::memcpy(&xf[i * 16], scene.gameObjects[i].transform.m, 64);
+        check(rz_update_transforms(ctx_, xf.data(), scene.gameObjects.size()), "rz_update_transforms");
+    }
     void sendSceneDataToShader(const Scene& scene, int width, int height, int bounceBudget, int spp = 1,
                                int sampleBase = 0, int tileRank = 0, int tileNRanks = 1) {
         rz_frame_params p{};

@@ -73,6 +73,21 @@ class Renderer:
         for b in (BIND_INSTANCES, BIND_TLAS_NODES, BIND_TLAS_INDICES):
             self.update(b, scene.arrays[b])
 
+    def update_transforms(self, transforms):
+        """Device-side updateDynamicBVHAndSSBOs: transforms = (n, 16) float32, column-major."""
+        t = np.ascontiguousarray(transforms, np.float32).reshape(-1, 16)
+        self._check(self._L.rz_update_transforms(self._c, t.ctypes.data, t.shape[0]), "rz_update_transforms")
+
+    def read_binding(self, binding):
+        """The binding's current content in RayZen's layout (what the device built, after update_transforms)."""
+        need = C.c_size_t(0)
+        self._check(self._L.rz_read_binding(self._c, int(binding), None, 0, C.byref(need)), "rz_read_binding")
+        dt = BINDING_DTYPES[int(binding)]
+        out = np.zeros(need.value // dt.itemsize, dt)
+        self._check(self._L.rz_read_binding(self._c, int(binding), out.ctypes.data if out.nbytes else None, out.nbytes,
+                                            C.byref(need)), "rz_read_binding")
+        return out
+
     # -- uniforms + draw -----------------------------------------------------
     def set_frame(self, params):
         self._check(self._L.rz_set_frame(self._c, C.byref(params)), "rz_set_frame")
