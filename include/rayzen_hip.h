@@ -149,9 +149,9 @@ typedef struct rz_ctx rz_ctx;
 /* glfwCreateWindow/MakeContextCurrent (main.cpp:228-241) / teardown (681-686).
  * device = HIP device ordinal.  flags: RZ_FLAG_* below.  Returns NULL on
  * failure (query rz_last_error(NULL)). */
-#define RZ_FLAG_NONE          0u
-#define RZ_FLAG_MEGAKERNEL    1u  /* force the one-thread-per-pixel kernel  */
-#define RZ_FLAG_WAVEFRONT     2u  /* force the queued wavefront pipeline    */
+#define RZ_FLAG_NONE          0u  /* default: one lane per sample (rz_render_samples)                         */
+#define RZ_FLAG_MEGAKERNEL    1u  /* one lane per pixel, samples in sequence (rz_render_pixels): cross-check  */
+#define RZ_FLAG_WAVEFRONT     2u  /* queued pipeline wf_init/wf_trace/wf_shade: bit-identical, slower, opt-in */
 rz_ctx*     rz_create(int device, unsigned flags);
 void        rz_destroy(rz_ctx* ctx);
 const char* rz_last_error(const rz_ctx* ctx);
@@ -225,8 +225,8 @@ int rz_last_render_ms(rz_ctx* ctx, float* ms, int* launches);
  * timed loop can issue its launches back to back and collect their GPU times afterwards. */
 int rz_render_history_ms(rz_ctx* ctx, float* ms, int cap);
 /* Name of the render kernel the last rz_render used (the one those event pairs bracket): the library picks
- * "rz_render_samples" (one lane per sample; scenes in which no triangle uses a transparent material) or
- * "rz_render_pixels" (one lane per pixel; any scene), or the queued pipeline if RZ_FLAG_WAVEFRONT was given. */
+ * "rz_render_samples" (one lane per sample; "rz_render_samples<glass>" when a triangle uses a transparent material
+ * and currentIor is speculated), "rz_render_pixels" (RZ_FLAG_MEGAKERNEL) or "wf_trace+wf_shade" (RZ_FLAG_WAVEFRONT). */
 const char* rz_last_kernel_name(const rz_ctx* ctx);
 
 /* Device pointer of the accumulation buffer currently in use. */

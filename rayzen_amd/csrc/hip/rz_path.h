@@ -42,7 +42,7 @@ struct Path {
     int iter;
     // the (at most two) terms this sample adds to the pixel's colour, in the shader's order: FS:717 then FS:709.
     // The one-lane-per-pixel kernel adds them to `color` on the spot and never reads these; the
-    // one-lane-per-sample kernel stores them and rz_sum_samples replays the adds in order.
+    // one-lane-per-sample kernel parks them in LDS and replays the adds in sample order (rz_kernels.hip).
     v3 addLight, addSky;
     int usedIor;        // this sample read (and possibly changed) currentIor: FS:727-742 executed
 };
