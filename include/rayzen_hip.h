@@ -215,6 +215,23 @@ int rz_read_accum(rz_ctx* ctx, float* rgba, size_t bytes);
  * Row 0 = bottom row.  Synchronises. */
 int rz_resolve_rgba8(rz_ctx* ctx, uint8_t* rgba8, size_t bytes);
 
+/* The rest of the shader's main() after the path loop (fragment_shader.glsl:772-819): resolve, then the overlays the
+ * reference draws on top -- BVH wireframe (debugShowBVH/debugBVHMode/debugSelectedBLAS/debugSelectedTri,
+ * glsl:98-104,214-373), light markers (debugShowLights, glsl:781-803) and the FPS digits (uniformFps, glsl:805-819;
+ * the reference always draws them) -- and 8-bit quantisation.  rgba8 (width*height*4 bytes) and rgb32f
+ * (width*height*3 floats: the colour before quantisation) may each be NULL.  Row 0 = bottom row.  Synchronises. */
+typedef struct rz_present_params {
+    float   fps;            /* uniformFps */
+    int32_t show_fps;       /* 1 = as the reference */
+    int32_t show_lights;    /* debugShowLights */
+    int32_t show_bvh;       /* debugShowBVH */
+    int32_t bvh_mode;       /* debugBVHMode: 0 = TLAS leaves + BLAS roots, 1 = branch to one triangle */
+    int32_t selected_blas;  /* debugSelectedBLAS (an instance index) */
+    int32_t selected_tri;   /* debugSelectedTri (mesh-local triangle id) */
+} rz_present_params;
+int rz_present(rz_ctx* ctx, const rz_present_params* params, uint8_t* rgba8, size_t rgba8_bytes, float* rgb32f,
+               size_t rgb32f_bytes);
+
 /* Wall-clock-free timing: milliseconds the render kernels of the LAST
  * rz_render spent on the GPU (HIP events on the stream they ran on), and how
  * many kernel launches that was.  Synchronises. */

@@ -80,6 +80,22 @@ int rzo_trace(const rzo_scene* scene, const float origin[3], const float dir[3],
 /* FS:507-528 */
 int rzo_shadow(const rzo_scene* scene, const float origin[3], const float dir[3], float maxDist, float* visibility);
 
+/* Presentation tail of the shader (FS:772-819): resolve + BVH wireframe + light markers + FPS digits. */
+typedef struct {
+    int32_t width, height;
+    float view[16], proj[16];            /* camera.viewMatrix / projectionMatrix, column-major */
+    int32_t num_lights;                  /* uniform numLights */
+    float fps;                           /* uniformFps */
+    int32_t show_fps;                    /* the shader always draws it; 0 switches it off */
+    int32_t show_lights;                 /* debugShowLights */
+    int32_t show_bvh;                    /* debugShowBVH */
+    int32_t bvh_mode;                    /* debugBVHMode: 0 TLAS leaves + BLAS roots, 1 branch to a triangle */
+    int32_t selected_blas, selected_tri; /* debugSelectedBLAS / debugSelectedTri */
+} rzo_present_params;
+/* accum: width*height*4 floats (rgb sums, a = sample count).  rgb_out (3 floats per pixel) and rgba8_out may be NULL. */
+int rzo_present(const rzo_scene* scene, const rzo_present_params* pp, const float* accum, float* rgb_out,
+                unsigned char* rgba8_out);
+
 /* The pinned built-ins, exported for the math tests. */
 float rzo_sin_f(float x);
 float rzo_cos_f(float x);

@@ -44,13 +44,21 @@ class _Frame(C.Structure):
                 ("spp", C.c_int32), ("sample_base", C.c_int32)]
 
 
+class _Present(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("view", C.c_float * 16), ("proj", C.c_float * 16),
+                ("num_lights", C.c_int32), ("fps", C.c_float), ("show_fps", C.c_int32), ("show_lights", C.c_int32),
+                ("show_bvh", C.c_int32), ("bvh_mode", C.c_int32), ("selected_blas", C.c_int32),
+                ("selected_tri", C.c_int32)]
+
+
 class _Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in COUNTER_FIELDS]
 
 
 def build(force=False):
     """Compile the oracle with its Makefile (gcc only; no GPU needed)."""
-    srcs = [os.path.join(_HERE, f) for f in ("rz_oracle.c", "rz_oracle_bvh.c", "rz_oracle.h", "rz_oracle_math.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("rz_oracle.c", "rz_oracle_bvh.c", "rz_oracle_present.c", "rz_oracle.h",
+                                            "rz_oracle_math.h", "Makefile")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -70,6 +78,8 @@ def lib():
         L.rzo_render.restype = C.c_int
         L.rzo_render.argtypes = [C.POINTER(_Scene), C.POINTER(_Frame), C.c_void_p, C.c_void_p,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_Counters)]
+        L.rzo_present.restype = C.c_int
+        L.rzo_present.argtypes = [C.POINTER(_Scene), C.POINTER(_Present), C.c_void_p, C.c_void_p, C.c_void_p]
         L.rzo_trace.restype = C.c_int
         L.rzo_trace.argtypes = [C.POINTER(_Scene), C.c_void_p, C.c_void_p, C.c_void_p]
         L.rzo_shadow.restype = C.c_int
@@ -143,6 +153,26 @@ def render(scene, frame, accum=None, ior_state=None, crop=None, nthreads=1, want
     if want_counters:
         return accum, {n: int(getattr(cnt, n)) for n in COUNTER_FIELDS}
     return accum
+
+
+def present(scene, accum, view, proj, num_lights, fps=0.0, show_fps=True, show_lights=False, show_bvh=False,
+            bvh_mode=0, selected_blas=0, selected_tri=0):
+    """FS:772-819 on an accumulation buffer (H, W, 4).  Returns (rgb float32 (H,W,3), rgba8 uint8 (H,W,4))."""
+    H, W = accum.shape[:2]
+    p = _Present()
+    p.width, p.height = W, H
+    p.view[:] = [float(x) for x in np.asarray(view, np.float32).reshape(16)]
+    p.proj[:] = [float(x) for x in np.asarray(proj, np.float32).reshape(16)]
+    p.num_lights, p.fps = int(num_lights), float(fps)
+    p.show_fps, p.show_lights, p.show_bvh = int(bool(show_fps)), int(bool(show_lights)), int(bool(show_bvh))
+    p.bvh_mode, p.selected_blas, p.selected_tri = int(bvh_mode), int(selected_blas), int(selected_tri)
+    acc = np.ascontiguousarray(accum, np.float32)
+    rgb = np.zeros((H, W, 3), np.float32)
+    rgba8 = np.zeros((H, W, 4), np.uint8)
+    rc = lib().rzo_present(C.byref(scene.c), C.byref(p), acc.ctypes.data, rgb.ctypes.data, rgba8.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("rzo_present failed")
+    return rgb, rgba8
 
 
 def algorithmic_bytes(c):

@@ -15,7 +15,7 @@ HIP_SYMBOLS = (
     "rz_create", "rz_destroy", "rz_last_error", "rz_upload", "rz_update", "rz_update_transforms", "rz_read_binding",
     "rz_set_frame", "rz_set_stream",
     "rz_bind_accum", "rz_render", "rz_render_counted", "rz_sync", "rz_clear_accum", "rz_read_accum",
-    "rz_resolve_rgba8", "rz_last_render_ms", "rz_render_history_ms", "rz_last_kernel_name", "rz_accum_device_ptr", "rz_version", "rz_sizeof",
+    "rz_resolve_rgba8", "rz_present", "rz_last_render_ms", "rz_render_history_ms", "rz_last_kernel_name", "rz_accum_device_ptr", "rz_version", "rz_sizeof",
 )
 # the symbols include/rayzen_host.h declares
 HOST_SYMBOLS = (
@@ -41,6 +41,12 @@ class FrameParams(C.Structure):
 
 COUNTER_FIELDS = ("samples", "traversals", "tlas_nodes", "tlas_leaf_indices", "instances",
                   "blas_nodes", "triangles", "materials", "light_fetches", "pixels")
+
+
+class PresentParams(C.Structure):
+    """rz_present_params of include/rayzen_hip.h."""
+    _fields_ = [("fps", C.c_float), ("show_fps", C.c_int32), ("show_lights", C.c_int32), ("show_bvh", C.c_int32),
+                ("bvh_mode", C.c_int32), ("selected_blas", C.c_int32), ("selected_tri", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -77,6 +83,7 @@ def hip():
         L.rz_clear_accum.restype, L.rz_clear_accum.argtypes = i, [vp]
         L.rz_read_accum.restype, L.rz_read_accum.argtypes = i, [vp, vp, sz]
         L.rz_resolve_rgba8.restype, L.rz_resolve_rgba8.argtypes = i, [vp, vp, sz]
+        L.rz_present.restype, L.rz_present.argtypes = i, [vp, C.POINTER(PresentParams), vp, sz, vp, sz]
         L.rz_last_render_ms.restype, L.rz_last_render_ms.argtypes = i, [vp, C.POINTER(C.c_float), C.POINTER(i)]
         L.rz_render_history_ms.restype, L.rz_render_history_ms.argtypes = i, [vp, C.POINTER(C.c_float), i]
         L.rz_last_kernel_name.restype, L.rz_last_kernel_name.argtypes = C.c_char_p, [vp]

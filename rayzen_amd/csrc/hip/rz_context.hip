@@ -36,6 +36,13 @@ void dump_wave_log(int nWaves);
 void launch_render_pixels(const KParams& K, bool counted, hipStream_t stream);
 void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream_t stream);
 void launch_resolve(const float4* accum, uchar4* out, int n, hipStream_t stream);
+struct PresentParams {      // rz_present.hip
+    const float4* accum; uchar4* rgba8; float* rgb; const TlasNode* tlasNodes; const int32_t* tlasIndices;
+    const DevInstance* instances; const DevLight* lights; int width, height; int nTlasNodes, nInstances, nLights;
+    float viewProj[16]; float fps; int showFps, showLights, showBvh, bvhMode; int pathLen;
+    float pathMin[32][3], pathMax[32][3]; float selTransform[16];
+};
+void launch_present(const PresentParams& P, hipStream_t s);
 }  // namespace rz
 
 using namespace rz;
@@ -822,6 +829,86 @@ int rz_resolve_rgba8(rz_ctx* c, uint8_t* rgba8, size_t bytes) {
     launch_resolve(static_cast<const float4*>(rz_accum_device_ptr(c)), static_cast<uchar4*>(c->dResolve.p), (int)nPix, c->stream);
     RZ_HIP(c, hipGetLastError());
     RZ_HIP(c, hipMemcpyAsync(rgba8, c->dResolve.p, nPix * 4, hipMemcpyDeviceToHost, c->stream));
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    return RZ_OK;
+}
+
+int rz_present(rz_ctx* c, const rz_present_params* pp, uint8_t* rgba8, size_t rgba8_bytes, float* rgb32f, size_t rgb32f_bytes) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    if (!pp) return fail(c, RZ_ERR_INVALID_ARG, "null params");
+    if (!c->haveFrame) return fail(c, RZ_ERR_NOT_READY, "rz_set_frame has not been called");
+    RZ_HIP(c, hipSetDevice(c->device));
+    int rc = finalize(c);
+    if (rc != RZ_OK) return rc;
+    const size_t nPix = (size_t)c->frame.width * c->frame.height;
+    if (rgba8 && rgba8_bytes < nPix * 4) return fail(c, RZ_ERR_BUFFER_SIZE, "rgba8 buffer needs %zu bytes", nPix * 4);
+    if (rgb32f && rgb32f_bytes < nPix * 12) return fail(c, RZ_ERR_BUFFER_SIZE, "rgb32f buffer needs %zu bytes", nPix * 12);
+    rc = ensure(c, c->dResolve, nPix * 4 + nPix * 12);
+    if (rc != RZ_OK) return rc;
+    PresentParams P{};
+    P.accum = static_cast<const float4*>(rz_accum_device_ptr(c));
+    P.rgba8 = static_cast<uchar4*>(c->dResolve.p);
+    P.rgb = reinterpret_cast<float*>(static_cast<char*>(c->dResolve.p) + nPix * 4);
+    P.tlasNodes = static_cast<const TlasNode*>(c->dTlasNodes.p);
+    P.tlasIndices = static_cast<const int32_t*>(c->dTlasIdx.p);
+    P.instances = static_cast<const DevInstance*>(c->dInst.p);
+    P.lights = static_cast<const DevLight*>(c->dLight.p);
+    P.width = c->frame.width; P.height = c->frame.height;
+    P.nTlasNodes = c->deviceOwnsTlas ? c->devTlasNodes : (int)hostCount<rz_bvh_node>(c, RZ_BIND_TLAS_NODES);
+    P.nInstances = (int)hostCount<rz_bvh_instance>(c, RZ_BIND_INSTANCES);
+    P.nLights = std::max(0, std::min<int>(c->frame.num_lights, (int)hostCount<rz_light>(c, RZ_BIND_LIGHTS)));
+    // camera.projectionMatrix * camera.viewMatrix, terms summed left to right (glsl:321)
+    const float* A = c->frame.proj; const float* B = c->frame.view;
+    for (int col = 0; col < 4; ++col)
+        for (int row = 0; row < 4; ++row)
+            P.viewProj[col * 4 + row] = ((A[0 * 4 + row] * B[col * 4 + 0] + A[1 * 4 + row] * B[col * 4 + 1]) +
+                                         A[2 * 4 + row] * B[col * 4 + 2]) + A[3 * 4 + row] * B[col * 4 + 3];
+    P.fps = pp->fps; P.showFps = pp->show_fps; P.showLights = pp->show_lights; P.showBvh = pp->show_bvh; P.bvhMode = pp->bvh_mode;
+    P.pathLen = 0;
+    if (pp->show_bvh && pp->bvh_mode == 1 && pp->selected_blas >= 0 && pp->selected_blas < P.nInstances) {
+        // findBVHBranchIterative (glsl:257-307) does not depend on the pixel: walk it once here
+        if (c->deviceOwnsTlas) { rc = sync_host_from_device(c); if (rc != RZ_OK) return rc; c->deviceOwnsTlas = true; }
+        const rz_bvh_instance* inst = hostArr<rz_bvh_instance>(c, RZ_BIND_INSTANCES);
+        const rz_bvh_node* nodes = hostArr<rz_bvh_node>(c, RZ_BIND_BLAS_NODES);
+        const int32_t* idx = hostArr<int32_t>(c, RZ_BIND_BLAS_INDICES);
+        const long long nNodes = (long long)hostCount<rz_bvh_node>(c, RZ_BIND_BLAS_NODES), nIdx = (long long)hostCount<int32_t>(c, RZ_BIND_BLAS_INDICES);
+        const rz_bvh_instance& S = inst[pp->selected_blas];
+        const int nodeOffset = S.blasNodeOffset, triOffset = S.blasTriOffset;
+        const int nodeCount = (pp->selected_blas + 1 < P.nInstances) ? inst[pp->selected_blas + 1].blasNodeOffset - nodeOffset : (int)nNodes - nodeOffset;
+        auto leafHas = [&](const rz_bvh_node& n) {
+            for (int k = 0; k < n.count; ++k) { long long j = (long long)triOffset + n.leftFirst + k; if (j >= 0 && j < nIdx && idx[j] == pp->selected_tri) return true; }
+            return false;
+        };
+        int path[32], len = 0, cur = 0;
+        for (int depth = 0; depth < 32; ++depth) {
+            path[len++] = cur;
+            if ((long long)nodeOffset + cur < 0 || (long long)nodeOffset + cur >= nNodes) { len = 0; break; }
+            const rz_bvh_node& node = nodes[nodeOffset + cur];
+            if (node.count > 0) { if (!leafHas(node)) len = 0; break; }
+            bool inLeft = false;
+            int stack[32], sp = 0;
+            stack[sp++] = node.leftFirst;
+            while (sp > 0) {
+                const int nidx = stack[--sp];
+                if (nidx < 0 || nidx >= nodeCount || (long long)nodeOffset + nidx >= nNodes) continue;
+                const rz_bvh_node& n = nodes[nodeOffset + nidx];
+                if (n.count > 0) inLeft = leafHas(n);
+                else if (sp + 2 <= 32) { stack[sp++] = n.leftFirst; stack[sp++] = n.leftFirst + 1; }
+                if (inLeft) break;
+            }
+            cur = inLeft ? node.leftFirst : node.leftFirst + 1;
+        }
+        P.pathLen = len;
+        for (int k = 0; k < len; ++k) {
+            std::memcpy(P.pathMin[k], nodes[nodeOffset + path[k]].boundsMin, 12);
+            std::memcpy(P.pathMax[k], nodes[nodeOffset + path[k]].boundsMax, 12);
+        }
+        std::memcpy(P.selTransform, S.transform, 64);
+    }
+    launch_present(P, c->stream);
+    RZ_HIP(c, hipGetLastError());
+    if (rgba8) RZ_HIP(c, hipMemcpyAsync(rgba8, P.rgba8, nPix * 4, hipMemcpyDeviceToHost, c->stream));
+    if (rgb32f) RZ_HIP(c, hipMemcpyAsync(rgb32f, P.rgb, nPix * 12, hipMemcpyDeviceToHost, c->stream));
     RZ_HIP(c, hipStreamSynchronize(c->stream));
     return RZ_OK;
 }

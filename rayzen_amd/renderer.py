@@ -124,6 +124,17 @@ class Renderer:
         self._check(self._L.rz_resolve_rgba8(self._c, out.ctypes.data, out.nbytes), "rz_resolve_rgba8")
         return out
 
+    def present(self, fps=0.0, show_fps=True, show_lights=False, show_bvh=False, bvh_mode=0, selected_blas=0,
+                selected_tri=0):
+        """fragment_shader.glsl:772-819: resolve + overlays.  Returns (rgb float32 (H,W,3), rgba8 uint8 (H,W,4))."""
+        p = _lib.PresentParams(float(fps), int(bool(show_fps)), int(bool(show_lights)), int(bool(show_bvh)),
+                               int(bvh_mode), int(selected_blas), int(selected_tri))
+        rgb = np.empty((self.height, self.width, 3), np.float32)
+        rgba8 = np.empty((self.height, self.width, 4), np.uint8)
+        self._check(self._L.rz_present(self._c, C.byref(p), rgba8.ctypes.data, rgba8.nbytes, rgb.ctypes.data,
+                                       rgb.nbytes), "rz_present")
+        return rgb, rgba8
+
     def last_render_ms(self):
         ms, n = C.c_float(0), C.c_int(0)
         self._check(self._L.rz_last_render_ms(self._c, C.byref(ms), C.byref(n)), "rz_last_render_ms")

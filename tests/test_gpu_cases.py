@@ -315,3 +315,28 @@ def test_device_tlas_matches_host_for_random_transforms(n):
     for b in (S.BIND_INSTANCES, S.BIND_TLAS_NODES, S.BIND_TLAS_INDICES):
         assert r.read_binding(b).tobytes() == sc.arrays[b].tobytes(), b
     r.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(fps=142.7), dict(fps=7.25, show_lights=True), dict(fps=999.94, show_bvh=True, bvh_mode=0, show_lights=True),
+    dict(fps=60.0, show_bvh=True, bvh_mode=1, selected_blas=2, selected_tri=17),
+    dict(fps=0.0, show_fps=False, show_bvh=True, bvh_mode=1, selected_blas=1, selected_tri=10 ** 6),   # not found: no path
+])
+def test_present_stage_matches_the_shader_tail(kw):
+    """FS:772-819 (resolve + BVH wireframe + light markers + FPS digits): HIP kernel vs oracle, float AND 8-bit."""
+    from oracle import rzo
+    from helpers import oracle_scene
+    from rayzen_amd.renderer import Renderer
+    sc = S.instanced_scene(n=8, count=4)
+    W, H = 200, 112
+    r = Renderer(0)
+    r.upload_scene(sc)
+    r.render_scene(sc, W, H, 2, 3)
+    acc = r.read_accum()
+    rgb, rgba8 = r.present(**kw)
+    want_rgb, want_rgba8 = rzo.present(oracle_scene(sc), acc, sc.camera.view, sc.camera.proj, len(sc.lights), **kw)
+    r.close()
+    assert (rgb.view(np.uint32) == want_rgb.view(np.uint32)).all(), float(np.abs(rgb - want_rgb).max())
+    assert (rgba8 == want_rgba8).all()
+    if kw.get("show_fps", True):
+        assert (rgba8[H - 24:H - 8, 8:100, :3] == 255).any()          # white digits in the top-left box
