@@ -40,7 +40,7 @@ struct PresentParams {      // rz_present.hip
     const float4* accum; uchar4* rgba8; float* rgb; const TlasNode* tlasNodes; const int32_t* tlasIndices;
     const DevInstance* instances; const DevLight* lights; int width, height; int nTlasNodes, nInstances, nLights;
     float viewProj[16]; float fps; int showFps, showLights, showBvh, bvhMode; int pathLen;
-    float pathMin[32][3], pathMax[32][3]; float selTransform[16];
+    float pathMin[32][3], pathMax[32][3]; float selTransform[16]; void* boxes;
 };
 void launch_present(const PresentParams& P, hipStream_t s);
 }  // namespace rz
@@ -119,7 +119,7 @@ struct rz_ctx {
     // queued pipeline (rz_wavefront.hip)
     DevBuf wfState, wfQueues, wfCounts;
     // device-side dynamic update (rz_update_transforms)
-    DevBuf dXforms, dInstRef, dTlasScratch;
+    DevBuf dXforms, dInstRef, dTlasScratch, dProjBoxes;
     int* tlasHostCounts = nullptr;      // pinned: node count, index count, depth
     bool deviceOwnsTlas = false;        // instances + TLAS on the device are newer than the host copies
     int devTlasNodes = 0;
@@ -623,7 +623,7 @@ void rz_destroy(rz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
-                      &c->dCounters, &c->dResolve, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts, &c->dXforms, &c->dInstRef, &c->dTlasScratch})
+                      &c->dCounters, &c->dResolve, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes})
         b->release();
     if (c->wfHostCount) (void)hipHostFree(c->wfHostCount);
     if (c->tlasHostCounts) (void)hipHostFree(c->tlasHostCounts);
@@ -904,6 +904,12 @@ int rz_present(rz_ctx* c, const rz_present_params* pp, uint8_t* rgba8, size_t rg
             std::memcpy(P.pathMax[k], nodes[nodeOffset + path[k]].boundsMax, 12);
         }
         std::memcpy(P.selTransform, S.transform, 64);
+    }
+    {   // projected-corner cache: one 112-B record per box a pixel may draw
+        const size_t nBoxes = (size_t)P.nTlasNodes + (size_t)P.nInstances + 32;
+        rc = ensure(c, c->dProjBoxes, nBoxes * 112);
+        if (rc != RZ_OK) return rc;
+        P.boxes = c->dProjBoxes.p;
     }
     launch_present(P, c->stream);
     RZ_HIP(c, hipGetLastError());

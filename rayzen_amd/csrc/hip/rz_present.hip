@@ -28,7 +28,14 @@ struct PresentParams {
     int pathLen;                // bvhMode 1: nodes on the branch to the selected triangle
     float pathMin[32][3], pathMax[32][3];   // their object-space boxes
     float selTransform[16];     // the selected instance's transform
+    struct ProjBox* boxes;      // screen-space corners of every box a pixel may have to draw, projected ONCE
 };
+
+// The 8 projected corners of one box (FS:243-249 for both endpoints of every edge) do not depend on the pixel:
+// rz_project_boxes computes them once per frame with the very same operations, plus a conservative screen-space
+// bounding rectangle (valid corners only, grown by the line thickness and a 1-px guard against rounding) that lets a
+// pixel skip a box none of whose edges can come within `thickness` of it.
+struct ProjBox { float sx[8], sy[8], sw[8]; float lox, loy, hix, hiy; };
 
 __constant__ int kFontRows[11][8] = {
     {0x3C, 0x66, 0x6E, 0x7E, 0x76, 0x66, 0x3C, 0x00}, {0x18, 0x38, 0x18, 0x18, 0x18, 0x18, 0x3C, 0x00},
@@ -59,28 +66,61 @@ __device__ __forceinline__ float seg_dist(float px, float py, float ax, float ay
     const float dx = px - (ax + t * abx), dy = py - (ay + t * aby);
     return __builtin_sqrtf(dx * dx + dy * dy);
 }
-// FS:229-254
-__device__ float box_wire(const float* mn, const float* mx, const float* vp, float fx, float fy, float thickness,
-                          float resx, float resy) {
-    float sx[8], sy[8], sw[8];
+// FS:229-254, first half: project the corners
+__device__ void project_box(const float* mn, const float* mx, const float* vp, float thickness, float resx, float resy,
+                            ProjBox& B) {
+    float lox = 3.0e38f, loy = 3.0e38f, hix = -3.0e38f, hiy = -3.0e38f;
     for (int c = 0; c < 8; ++c) {
         // corner order of FS:232-239
         const float x = (c == 1 || c == 2 || c == 5 || c == 6) ? mx[0] : mn[0];
         const float y = (c == 2 || c == 3 || c == 6 || c == 7) ? mx[1] : mn[1];
         const float z = (c >= 4) ? mx[2] : mn[2];
         const float4 q = m4v(vp, x, y, z, 1.0f);
-        sw[c] = q.w;
-        sx[c] = (q.x / q.w * 0.5f + 0.5f) * resx;
-        sy[c] = (q.y / q.w * 0.5f + 0.5f) * resy;
+        B.sw[c] = q.w;
+        B.sx[c] = (q.x / q.w * 0.5f + 0.5f) * resx;
+        B.sy[c] = (q.y / q.w * 0.5f + 0.5f) * resy;
+        if (q.w > 0.0f) {
+            lox = fmin_(lox, B.sx[c]); hix = fmax_(hix, B.sx[c]);
+            loy = fmin_(loy, B.sy[c]); hiy = fmax_(hiy, B.sy[c]);
+        }
     }
+    // NaN/inf corners: keep the box (rectangle = everything)
+    const bool finite = (lox - lox == 0.0f) && (hix - hix == 0.0f) && (loy - loy == 0.0f) && (hiy - hiy == 0.0f);
+    const float g = thickness + 1.0f;
+    B.lox = finite ? lox - g : -3.0e38f; B.hix = finite ? hix + g : 3.0e38f;
+    B.loy = finite ? loy - g : -3.0e38f; B.hiy = finite ? hiy + g : 3.0e38f;
+}
+// FS:229-254, second half: distance of this pixel to the 12 edges
+__device__ __forceinline__ float box_wire(const ProjBox& B, float fx, float fy, float thickness) {
+    if (fx < B.lox || fx > B.hix || fy < B.loy || fy > B.hiy) return 0.0f;
     const int e0[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, e1[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
     float best = 1e6f;
     for (int i = 0; i < 12; ++i) {
         const int a = e0[i], b = e1[i];
-        if (sw[a] <= 0.0f || sw[b] <= 0.0f) continue;
-        best = fmin_(best, seg_dist(fx, fy, sx[a], sy[a], sx[b], sy[b]));
+        if (B.sw[a] <= 0.0f || B.sw[b] <= 0.0f) continue;
+        best = fmin_(best, seg_dist(fx, fy, B.sx[a], B.sy[a], B.sx[b], B.sy[b]));
     }
     return best < thickness ? 1.0f : 0.0f;
+}
+
+// boxes[0 .. nTlasNodes) = TLAS nodes (leaves only are used), then nInstances BLAS roots, then pathLen path boxes
+__global__ void rz_project_boxes(const PresentParams P) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const float resx = (float)P.width, resy = (float)P.height;
+    const int nT = P.bvhMode == 0 ? P.nTlasNodes : 0, nI = P.bvhMode == 0 ? P.nInstances : 0;
+    if (k < nT) {
+        const TlasNode nd = P.tlasNodes[k];
+        project_box(nd.bmin, nd.bmax, P.viewProj, 1.5f, resx, resy, P.boxes[k]);
+    } else if (k < nT + nI) {
+        const DevInstance& I = P.instances[k - nT];
+        project_box(I.rootMin, I.rootMax, P.viewProj, 2.0f, resx, resy, P.boxes[k]);
+    } else if (k < nT + nI + P.pathLen) {
+        const int j = k - nT - nI;
+        const float4 ta = m4v(P.selTransform, P.pathMin[j][0], P.pathMin[j][1], P.pathMin[j][2], 1.0f);
+        const float4 tb = m4v(P.selTransform, P.pathMax[j][0], P.pathMax[j][1], P.pathMax[j][2], 1.0f);
+        const float mn[3] = {ta.x, ta.y, ta.z}, mx[3] = {tb.x, tb.y, tb.z};
+        project_box(mn, mx, P.viewProj, 2.0f, resx, resy, P.boxes[k]);
+    }
 }
 // FS:152-161
 __device__ __forceinline__ float glyph_at(int ch, float fx, float fy, float posx, float posy, float scale) {
@@ -106,7 +146,7 @@ __global__ __launch_bounds__(256) void rz_present_kernel(const PresentParams P) 
             for (int k = 0; k < P.nTlasNodes; ++k) {
                 const TlasNode nd = P.tlasNodes[k];
                 if (nd.count > 0) {
-                    const float w = box_wire(nd.bmin, nd.bmax, P.viewProj, fx, fy, 1.5f, resx, resy);
+                    const float w = box_wire(P.boxes[k], fx, fy, 1.5f);
                     if (w > 0.0f) {
                         const int meshIdx = P.tlasIndices[nd.leftFirst];
                         if (meshIdx < 0 || meshIdx >= P.nInstances) continue;
@@ -117,7 +157,7 @@ __global__ __launch_bounds__(256) void rz_present_kernel(const PresentParams P) 
                 }
             }
             for (int k = 0; k < P.nInstances; ++k) {
-                const float w = box_wire(P.instances[k].rootMin, P.instances[k].rootMax, P.viewProj, fx, fy, 2.0f, resx, resy);
+                const float w = box_wire(P.boxes[P.nTlasNodes + k], fx, fy, 2.0f);
                 if (w > 0.0f) {
                     blasColor = mixv(blasColor, mk3(0, 0, 0), w);
                     blasWire = fmax_(blasWire, w);
@@ -125,10 +165,7 @@ __global__ __launch_bounds__(256) void rz_present_kernel(const PresentParams P) 
             }
         } else if (P.bvhMode == 1) {
             for (int k = 0; k < P.pathLen; ++k) {
-                const float4 ta = m4v(P.selTransform, P.pathMin[k][0], P.pathMin[k][1], P.pathMin[k][2], 1.0f);
-                const float4 tb = m4v(P.selTransform, P.pathMax[k][0], P.pathMax[k][1], P.pathMax[k][2], 1.0f);
-                const float mn[3] = {ta.x, ta.y, ta.z}, mx[3] = {tb.x, tb.y, tb.z};
-                const float w = box_wire(mn, mx, P.viewProj, fx, fy, 2.0f, resx, resy);
+                const float w = box_wire(P.boxes[k], fx, fy, 2.0f);
                 blasWire = fmax_(blasWire, w);
                 blasColor = mixv(blasColor, hsv_to_rgb((float)k / (float)P.pathLen, 1.0f, 1.0f), w);
             }
@@ -166,10 +203,12 @@ __global__ __launch_bounds__(256) void rz_present_kernel(const PresentParams P) 
             col = mixv(col, mk3(1.0f, 1.0f, 1.0f), glyph_at(ch, fx, fy, posx + (float)(k * 9) * scale, posy + 0.0f, scale));
         }
         // FS:810-818: the 48 x 8 grid of 2-px cells the digits live in
+        // (cells sit at posx + 2x, posy + 2y: outside their hull grown by 1 px no cell can match)
         float any = 0.0f;
-        for (int y = 0; y < 8; ++y)
-            for (int x = 0; x < 48; ++x)
-                if (__builtin_fabsf(fx - (posx + (float)x * scale)) < 1.0f && __builtin_fabsf(fy - (posy + (float)y * scale)) < 1.0f) any = 1.0f;
+        if (fx > posx - 2.0f && fx < posx + 96.0f && fy > posy - 2.0f && fy < posy + 16.0f)
+            for (int y = 0; y < 8; ++y)
+                for (int x = 0; x < 48; ++x)
+                    if (__builtin_fabsf(fx - (posx + (float)x * scale)) < 1.0f && __builtin_fabsf(fy - (posy + (float)y * scale)) < 1.0f) any = 1.0f;
         color = mixv(color, col, any);
     }
     if (P.rgb) { P.rgb[3 * (size_t)i] = color.x; P.rgb[3 * (size_t)i + 1] = color.y; P.rgb[3 * (size_t)i + 2] = color.z; }
@@ -180,6 +219,8 @@ __global__ __launch_bounds__(256) void rz_present_kernel(const PresentParams P) 
 }
 
 void launch_present(const PresentParams& P, hipStream_t s) {
+    const int nBoxes = P.showBvh ? (P.bvhMode == 0 ? P.nTlasNodes + P.nInstances : P.pathLen) : 0;
+    if (nBoxes > 0) hipLaunchKernelGGL(rz_project_boxes, dim3((nBoxes + 63) / 64), dim3(64), 0, s, P);
     const int n = P.width * P.height;
     hipLaunchKernelGGL(rz_present_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P);
 }
