@@ -95,16 +95,21 @@ def main():
     fp = frame_params(sc.camera, W, H, len(sc.lights), bounces, spp_total, 0, rank, world)
     r.set_frame(fp)
 
+    # N > 1: `accum` is this rank's private buffer (its non-owned pixels stay zero for ever); each step copies it to
+    # `frame` and reduces THAT in place, so rank 0's sum never leaks into the next step's input.
+    frame = torch.empty_like(accum) if world > 1 else accum
+
     def step():
         r.render()                      # async on torch's current stream
         if world > 1:
+            frame.copy_(accum)
             if a.dist_backend == "nccl":
-                rzdist.reduce_accum(accum, dst=0)          # one RCCL reduce(SUM) of the 33 MB frame
+                rzdist.reduce_accum(frame, dst=0)          # one RCCL reduce(SUM) of the 33 MB frame
             else:                                           # rehearsal: same reduce, staged through the host
-                host = accum.cpu()
+                host = frame.cpu()
                 rzdist.reduce_accum(host, dst=0)
                 if rank == 0:
-                    accum.copy_(host)
+                    frame.copy_(host)
 
     def fence():
         if world > 1:
@@ -149,6 +154,11 @@ def main():
                    "parallelism": f"tiles8x8-roundrobin-x{world}" + (("+rccl-reduce" if a.dist_backend == "nccl" else "+gloo-reduce(rehearsal)") if world > 1 else "")},
     }
     if rank == 0:
+        # size-independent check of the sharding + reduce: every pixel of the final frame received exactly
+        # spp_total samples (a pixel rendered twice or not at all by the tile deal would show here)
+        cnt = frame[..., 3]
+        out["frame_check"] = {"every_pixel_has_spp_total_samples": bool((cnt == float(spp_total)).all().item()),
+                              "finite_and_nonnegative": bool((torch.isfinite(frame).all() & (frame >= 0).all()).item())}
         ach = alg_bytes / (kms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -188,7 +198,7 @@ def main():
             rows += 8
             bands.append(y0)
         cpu_samples = rows * W * a.spp
-        gpu = accum.cpu().numpy()       # last timed frame (sample_base 0 each step: a complete frame)
+        gpu = frame.cpu().numpy()       # last timed frame (sample_base 0 each step: a complete frame)
         err = 0.0
         same = 0
         tot = 0

@@ -75,3 +75,49 @@ def test_tile_sharded_render_plus_reduce_is_bit_identical_to_single_rank(tmp_pat
     got = np.load(out)
     want = oracle_render(S.cornell_scene(), W, H, spp, bounces, nthreads=2)
     assert (got.view(np.uint32) == want.view(np.uint32)).all()
+
+
+def _bench_like_worker(rank, world, port, out_path):
+    """The step() of bench.py with the oracle standing in for the GPU: private buffer -> copy -> in-place reduce,
+    repeated, must give the same frame every step (an in-place reduce straight on the render buffer would not)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from oracle import rzo
+    from rayzen_amd import scene as S
+    from helpers import oracle_frame, oracle_scene
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W, H = 40, 24
+    sc = S.cornell_scene()
+    osc, fr = oracle_scene(sc), oracle_frame(sc, W, H, 2, 2)
+    tx, ty = D.tile_grid(W, H)
+    accum = torch.zeros((H, W, 4), dtype=torch.float32)
+    frame = torch.empty_like(accum)
+    frames = []
+    for step in range(3):
+        a = accum.numpy()
+        for t in range(rank, tx * ty, world):
+            x0, y0 = (t % tx) * 8, (t // tx) * 8
+            rzo.render(osc, fr, accum=a, crop=(x0, y0, min(x0 + 8, W), min(y0 + 8, H)), nthreads=1)
+        frame.copy_(accum)
+        D.reduce_accum(frame, dst=0)
+        frames.append(frame.numpy().copy())
+    if rank == 0:
+        np.save(out_path, np.stack(frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_repeated_steps_reduce_to_the_same_frame(tmp_path):
+    import torch.multiprocessing as mp
+    from helpers import oracle_render
+    from rayzen_amd import scene as S
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_bench_like_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    frames = np.load(out)
+    want = oracle_render(S.cornell_scene(), 40, 24, 2, 2, nthreads=2)
+    for f in frames:
+        assert (f.view(np.uint32) == want.view(np.uint32)).all()
