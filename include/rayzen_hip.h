@@ -174,6 +174,13 @@ int rz_update(rz_ctx* ctx, rz_binding binding, size_t offset,
  * stream (the TLAS depth sizes the next launch). */
 int rz_update_transforms(rz_ctx* ctx, const float* transforms, size_t n);
 
+/* BVH::buildBLAS (RayZen/src/BVH.cpp:99-175 with the full-sweep SAH of :22-97; called per mesh from main.cpp:954-958)
+ * on the device.  Output is byte-identical to the reference builder's `nodes` / `triIndices`: nodes_out receives
+ * *n_nodes <= 2n-1 nodes (nodes_cap >= 2n-1, or 1 for n == 0), indices_out n triangle indices.  depth and device_ms
+ * (device time, host<->device copies excluded) may be NULL.  tris / outputs are host pointers. */
+int rz_build_blas(rz_ctx* ctx, const rz_triangle* tris, size_t n, rz_bvh_node* nodes_out, size_t nodes_cap,
+                  int32_t* indices_out, size_t* n_nodes, int* depth, float* device_ms);
+
 /* Copy a binding's current content back to the host in RayZen's own layout (after rz_update_transforms: the
  * instances / TLAS nodes / TLAS indices the device built).  out == NULL: only *needed is set. */
 int rz_read_binding(rz_ctx* ctx, rz_binding binding, void* out, size_t bytes, size_t* needed);

@@ -18,6 +18,7 @@
 #include <new>
 #include <string>
 #include <tuple>
+#include <limits>
 #include <vector>
 
 #include "rayzen_hip.h"
@@ -30,6 +31,10 @@ struct TlasWork {       // rz_tlas_device.hip
     float* worldMin; float* worldMax; int32_t* order; int32_t* stack; int32_t* outCounts; int n;
 };
 void launch_tlas_refit(const TlasWork& W, hipStream_t s);
+// rz_blas_device.hip
+size_t blas_build_workspace_bytes(size_t n);
+int blas_build_device(const rz_triangle* hostTris, size_t n, void* workspace, size_t workspaceBytes, rz_bvh_node* nodes_out,
+                      int32_t* idx_out, int* nNodesOut, int* depthOut, float* ms, hipStream_t s);
 #ifdef RZ_PROF
 void dump_wave_log(int nWaves);
 #endif
@@ -119,7 +124,7 @@ struct rz_ctx {
     // queued pipeline (rz_wavefront.hip)
     DevBuf wfState, wfQueues, wfCounts;
     // device-side dynamic update (rz_update_transforms)
-    DevBuf dXforms, dInstRef, dTlasScratch, dProjBoxes;
+    DevBuf dXforms, dInstRef, dTlasScratch, dProjBoxes, dBuildWs;
     int* tlasHostCounts = nullptr;      // pinned: node count, index count, depth
     bool deviceOwnsTlas = false;        // instances + TLAS on the device are newer than the host copies
     int devTlasNodes = 0;
@@ -623,7 +628,7 @@ void rz_destroy(rz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
-                      &c->dCounters, &c->dResolve, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes})
+                      &c->dCounters, &c->dResolve, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs})
         b->release();
     if (c->wfHostCount) (void)hipHostFree(c->wfHostCount);
     if (c->tlasHostCounts) (void)hipHostFree(c->tlasHostCounts);
@@ -724,6 +729,41 @@ int rz_update_transforms(rz_ctx* c, const float* transforms, size_t n) {
     c->devTlasNodes = c->tlasHostCounts[0];
     c->tlasDepth = std::max(1, c->tlasHostCounts[2]);
     c->deviceOwnsTlas = true;
+    return RZ_OK;
+}
+
+int rz_build_blas(rz_ctx* c, const rz_triangle* tris, size_t n, rz_bvh_node* nodes_out, size_t nodes_cap, int32_t* indices_out,
+                  size_t* n_nodes, int* depth, float* device_ms) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    if (n && !tris) return fail(c, RZ_ERR_INVALID_ARG, "null triangles");
+    if (!nodes_out || (n && !indices_out)) return fail(c, RZ_ERR_INVALID_ARG, "null output");
+    if (n > (size_t)1 << 30) return fail(c, RZ_ERR_INVALID_ARG, "too many triangles");
+    if (nodes_cap < (n ? 2 * n - 1 : 1)) return fail(c, RZ_ERR_BUFFER_SIZE, "nodes_out holds %zu nodes, up to %zu are needed", nodes_cap, n ? 2 * n - 1 : (size_t)1);
+    if (device_ms) *device_ms = 0.0f;
+    if (n == 0) {        // BVH.cpp:101-118 on an empty mesh: one root with an inverted box and no triangles
+        const float fmax = std::numeric_limits<float>::max();
+        rz_bvh_node r{};
+        for (int k = 0; k < 3; ++k) { r.boundsMin[k] = fmax; r.boundsMax[k] = -fmax; }
+        r.leftFirst = 0; r.count = 0;
+        nodes_out[0] = r;
+        if (n_nodes) *n_nodes = 1;
+        if (depth) *depth = 1;
+        return RZ_OK;
+    }
+    RZ_HIP(c, hipSetDevice(c->device));
+    const size_t ws = blas_build_workspace_bytes(n);
+    int rc = ensure(c, c->dBuildWs, ws);
+    if (rc != RZ_OK) return rc;
+    std::vector<rz_bvh_node> tmp;
+    try { tmp.resize(2 * n + 2); } catch (...) { return fail(c, RZ_ERR_HIP, "out of host memory"); }
+    int nn = 0, dp = 0;
+    const int e = blas_build_device(tris, n, c->dBuildWs.p, c->dBuildWs.cap, tmp.data(), indices_out, &nn, &dp, device_ms, c->stream);
+    if (e > 0) return fail(c, RZ_ERR_HIP, "device BLAS build: %s", hipGetErrorString((hipError_t)e));
+    if (e < 0) return fail(c, RZ_ERR_HIP, "device BLAS build: internal limit");
+    if ((size_t)nn > nodes_cap) return fail(c, RZ_ERR_BUFFER_SIZE, "nodes_out holds %zu nodes, %d were built", nodes_cap, nn);
+    std::memcpy(nodes_out, tmp.data(), (size_t)nn * sizeof(rz_bvh_node));
+    if (n_nodes) *n_nodes = (size_t)nn;
+    if (depth) *depth = dp;
     return RZ_OK;
 }
 

@@ -78,6 +78,20 @@ class Renderer:
         t = np.ascontiguousarray(transforms, np.float32).reshape(-1, 16)
         self._check(self._L.rz_update_transforms(self._c, t.ctypes.data, t.shape[0]), "rz_update_transforms")
 
+    def build_blas(self, triangles):
+        """BVH::buildBLAS (BVH.cpp:99-175, SAH) on the device.  triangles: TRIANGLE_DTYPE array.
+        Returns (nodes, indices, depth, device_ms); byte-identical to the reference builder's output."""
+        from .scene import BVH_NODE as NODE_DTYPE, TRIANGLE as TRIANGLE_DTYPE
+        t = np.ascontiguousarray(triangles, TRIANGLE_DTYPE)
+        n = t.shape[0]
+        nodes = np.zeros(max(2 * n - 1, 1), NODE_DTYPE)
+        idx = np.zeros(n, np.int32)
+        nn, depth, ms = C.c_size_t(0), C.c_int(0), C.c_float(0)
+        self._check(self._L.rz_build_blas(self._c, t.ctypes.data if n else None, n, nodes.ctypes.data, nodes.shape[0],
+                                          idx.ctypes.data if n else None, C.byref(nn), C.byref(depth), C.byref(ms)),
+                    "rz_build_blas")
+        return nodes[:nn.value].copy(), idx, depth.value, ms.value
+
     def read_binding(self, binding):
         """The binding's current content in RayZen's layout (what the device built, after update_transforms)."""
         need = C.c_size_t(0)
