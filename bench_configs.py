@@ -8,6 +8,7 @@
   c4d the same frames with rz_update_transforms: inverse, world AABBs and the TLAS rebuild run on the GPU
   c5  ~1M-triangle mesh, 3840x2160, 128 spp, 8 bounces (the per-GPU share of the 8-GPU config is 1/8 of the pixels;
       here one GPU renders the whole frame)
+  c5d the same with the BLAS built on the device (rz_build_blas) instead of by librayzen_host
 bench.py stays the driver-facing benchmark (configs[1]); this prints one JSON line per config.
 """
 import json
@@ -18,21 +19,22 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(_
 
 
 def main():
-    which = sys.argv[1:] or ["c1", "c4", "c4d", "c5"]
+    which = sys.argv[1:] or ["c1", "c4", "c4d", "c5", "c5d"]
     from rayzen_amd import scene as S
     from rayzen_amd.renderer import Renderer, algorithmic_bytes, frame_params
     for name in which:
+        r = Renderer(0)
         t_build = time.perf_counter()
         if name == "c1":
             sc, W, H, spp, b, frames = S.cornell_scene(), 256, 256, 4, 1, 20
         elif name in ("c4", "c4d"):
             sc, W, H, spp, b, frames = S.instanced_scene(n=76, count=16, aspect=1920 / 1080), 1920, 1080, 16, 4, 30
-        elif name == "c5":
-            sc, W, H, spp, b, frames = S.stress_scene(n=289, aspect=3840 / 2160), 3840, 2160, 128, 8, 3
+        elif name in ("c5", "c5d"):
+            sc = S.stress_scene(n=289, aspect=3840 / 2160, blas_builder=r if name == "c5d" else None)
+            W, H, spp, b, frames = 3840, 2160, 128, 8, 3
         else:
             raise SystemExit(name)
         t_build = time.perf_counter() - t_build
-        r = Renderer(0)
         floor_xf = sc.arrays[S.BIND_INSTANCES]["transform"][0].copy() if name == "c4d" else None
         t_up = time.perf_counter()
         r.upload_scene(sc)
@@ -61,7 +63,7 @@ def main():
                "ms_per_frame_wall": round(dt / frames * 1e3, 3), "kernel_ms": round(sum(kms) / len(kms), 3),
                "msamples_per_s": round(W * H * spp * frames / dt / 1e6, 1), "kernel": r.last_kernel_name(),
                "algorithmic_bytes_per_sample": round(algorithmic_bytes(cnt) / cnt["samples"], 1),
-               "host_scene_build_s": round(t_build, 3), "upload_relayout_first_frame_s": round(t_up, 3)}
+               "scene_build_s": round(t_build, 3), "upload_relayout_first_frame_s": round(t_up, 3)}
         print(json.dumps(out), flush=True)
         r.close()
 

@@ -45,7 +45,13 @@ int  rzh_scene_add_object(rzh_scene* s, int mesh_id, const float transform[16]);
 int  rzh_scene_set_transform(rzh_scene* s, int object_id, const float transform[16]);
 /* share_meshes = 0: one BLAS/triangle copy per object, exactly as the
  * reference; 1: one copy per distinct mesh (true instancing). */
-int  rzh_scene_build(rzh_scene* s, int share_meshes);
+int  rzh_scene_build(rzh_scene* s, int share_meshes);        /* -2: the BLAS builder set below failed */
+/* Replace BVH::buildBLAS inside rzh_scene_build by a function with rz_build_blas's signature (include/rayzen_hip.h;
+ * ctx = its rz_ctx*): the device builder, same bytes.  fn == NULL restores the host builder.  This library stays free
+ * of HIP: the caller passes the entry point. */
+typedef int (*rzh_blas_builder_fn)(void* ctx, const rz_triangle* tris, size_t n, rz_bvh_node* nodes_out, size_t nodes_cap,
+                                   int32_t* indices_out, size_t* n_nodes, int* depth, float* device_ms);
+int  rzh_scene_set_blas_builder(rzh_scene* s, rzh_blas_builder_fn fn, void* ctx);
 int  rzh_scene_update_dynamic(rzh_scene* s);
 /* pointer/size of a geometry array (bindings 0, 5, 6, 7, 8, 9); valid until
  * the next build/update/destroy */

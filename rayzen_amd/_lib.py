@@ -21,7 +21,7 @@ HIP_SYMBOLS = (
 HOST_SYMBOLS = (
     "rzh_load_obj", "rzh_build_blas", "rzh_build_tlas", "rzh_world_bounds", "rzh_scene_create",
     "rzh_scene_destroy", "rzh_scene_add_mesh", "rzh_scene_add_object", "rzh_scene_set_transform",
-    "rzh_scene_build", "rzh_scene_update_dynamic", "rzh_scene_buffer", "rzh_scene_depths",
+    "rzh_scene_build", "rzh_scene_set_blas_builder", "rzh_scene_update_dynamic", "rzh_scene_buffer", "rzh_scene_depths",
     "rzh_scene_save_cache", "rzh_scene_load_cache",
     "rzh_camera_matrices", "rzh_mat_translate", "rzh_mat_scale", "rzh_mat_rotate", "rzh_mat_inverse",
     "rzh_make_cube", "rzh_make_blob", "rzh_version",
@@ -113,6 +113,7 @@ def host():
         L.rzh_scene_add_object.restype, L.rzh_scene_add_object.argtypes = i, [vp, i, vp]
         L.rzh_scene_set_transform.restype, L.rzh_scene_set_transform.argtypes = i, [vp, i, vp]
         L.rzh_scene_build.restype, L.rzh_scene_build.argtypes = i, [vp, i]
+        L.rzh_scene_set_blas_builder.restype, L.rzh_scene_set_blas_builder.argtypes = i, [vp, vp, vp]
         L.rzh_scene_update_dynamic.restype, L.rzh_scene_update_dynamic.argtypes = i, [vp]
         L.rzh_scene_buffer.restype, L.rzh_scene_buffer.argtypes = vp, [vp, i, C.POINTER(sz)]
         L.rzh_scene_save_cache.restype, L.rzh_scene_save_cache.argtypes = i, [vp, C.c_char_p]

@@ -38,6 +38,7 @@ constexpr int BB_E = 8;                              // elements per thread per 
 constexpr int BB_CHUNK = BB_THREADS * BB_E;
 constexpr float BB_FMAX = 3.402823466e+38f;
 constexpr int BB_NOPOS = 0x7fffffff;
+constexpr int BB_LARGE = 4096;                       // nodes larger than this are spread over one workgroup per chunk
 constexpr int BB_SMALL = 64;                         // nodes this small are handled by one wave, lane = position
 
 struct BuildNode {
@@ -60,7 +61,19 @@ struct BlasBuild {
     BuildNode* nodes;                             // capacity 2n+1
     int* levelNodes[2];                           // build ids of the current / next level's nodes with more than BB_SMALL triangles
     int* smallNodes[2];                           // ... with at most BB_SMALL triangles (leaves included): one wave each
-    int* counters;                                // [0] nodes allocated, [1] next-level count, [2] max depth, [3] next-level small count
+    int* largeNodes[2];                           // ... with more than BB_LARGE triangles: one workgroup per 2048-position chunk
+    int* counters;                                // [0] nodes allocated; next level's counts: [1] medium, [3] small, [4] large
+    // large-node path: per level, chunk c of large node j is global chunk nodeChunkBase[j] + c
+    int* nodeChunkBase;                           // [maxLarge + 1]
+    float* chunkBox;                              // [4][maxC][6]: box of the chunk along axis 0..2; [3] = bounds partial in idx order
+    int* chunkPos;                                // [maxC][6]: position of the leftmost extremum of the bounds partial
+    float* chunkPre; float* chunkSuf;             // [3][maxC][6]: box of everything before / after the chunk
+    float* chunkBestCost; int* chunkBestAt;       // [3][maxC]: cheapest split inside the chunk
+    int* chunkLefts;                              // [3][maxC]: elements of the chunk that go left
+    float* nodeBox;                               // [maxLarge][6]
+    int* nodePick;                                // [maxLarge][4]: axis, split, mid, used SAH
+    float* rarea3[3];                             // suffix-box areas, all three axes at once
+    int maxC;
     rz_bvh_node* outNodes;                        // reference layout, reference order
 };
 
@@ -107,8 +120,8 @@ __global__ void bb_init_root(BlasBuild B) {
     BuildNode r{};
     r.start = 0; r.end = B.n; r.left = r.right = -1; r.depth = 1;
     B.nodes[0] = r;
-    (B.n <= BB_SMALL ? B.smallNodes[0] : B.levelNodes[0])[0] = 0;
-    B.counters[0] = 1; B.counters[1] = 0; B.counters[2] = 1; B.counters[3] = 0;
+    (B.n <= BB_SMALL ? B.smallNodes[0] : (B.n <= BB_LARGE ? B.levelNodes[0] : B.largeNodes[0]))[0] = 0;
+    B.counters[0] = 1; B.counters[1] = 0; B.counters[2] = 0; B.counters[3] = 0; B.counters[4] = 0;
 }
 
 struct Best { float cost; int axis; int i; };
@@ -132,10 +145,12 @@ __device__ __forceinline__ void push_children(const BlasBuild& B, int srcBuf, in
     R.start = mid; R.end = end; R.left = R.right = -1; R.depth = depth + 1;
     B.nodes[id0] = L; B.nodes[id0 + 1] = R;
     B.nodes[nodeId].left = id0; B.nodes[nodeId].right = id0 + 1;
-    if (mid - start <= BB_SMALL) B.smallNodes[srcBuf ^ 1][atomicAdd(&B.counters[3], 1)] = id0;
-    else B.levelNodes[srcBuf ^ 1][atomicAdd(&B.counters[1], 1)] = id0;
-    if (end - mid <= BB_SMALL) B.smallNodes[srcBuf ^ 1][atomicAdd(&B.counters[3], 1)] = id0 + 1;
-    else B.levelNodes[srcBuf ^ 1][atomicAdd(&B.counters[1], 1)] = id0 + 1;
+    for (int k = 0; k < 2; ++k) {
+        const int cn = k == 0 ? mid - start : end - mid;
+        if (cn <= BB_SMALL) B.smallNodes[srcBuf ^ 1][atomicAdd(&B.counters[3], 1)] = id0 + k;
+        else if (cn <= BB_LARGE) B.levelNodes[srcBuf ^ 1][atomicAdd(&B.counters[1], 1)] = id0 + k;
+        else B.largeNodes[srcBuf ^ 1][atomicAdd(&B.counters[4], 1)] = id0 + k;
+    }
 }
 
 // One chunk of a block-wide inclusive box scan.  loc[e] holds this thread's BB_E consecutive boxes on entry and
@@ -472,6 +487,347 @@ __global__ __launch_bounds__(BB_SMALL_THREADS) void bb_level_small(BlasBuild B, 
     }
 }
 
+// ---- 3c. nodes of more than BB_LARGE triangles: the same step, one workgroup per 2048-position chunk.  Chunk totals
+// are scanned per node into carries, so every chunk can run its part of the prefix / suffix scans on its own.
+__device__ __forceinline__ bool locate(const BlasBuild& B, int srcBuf, int nLarge, int c, int& j, int& nodeId, int& start, int& N, int& cl) {
+    if (c >= B.nodeChunkBase[nLarge]) return false;
+    int lo = 0, hi = nLarge - 1;
+    while (lo < hi) { const int m = (lo + hi + 1) >> 1; if (B.nodeChunkBase[m] <= c) lo = m; else hi = m - 1; }
+    j = lo; nodeId = B.largeNodes[srcBuf][j];
+    start = B.nodes[nodeId].start; N = B.nodes[nodeId].end - start; cl = c - B.nodeChunkBase[j];
+    return true;
+}
+__device__ __forceinline__ void load_box(const BlasBuild& B, int id, float* b) {
+    for (int k = 0; k < 3; ++k) { b[k] = B.tmin[3 * id + k]; b[3 + k] = B.tmax[3 * id + k]; }
+}
+// thread 0 ends up with the block's merged box
+__device__ __forceinline__ void block_reduce_box(float* b, float (*sWave)[6]) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int off = 32; off > 0; off >>= 1) {
+        float o[6];
+        for (int c = 0; c < 6; ++c) o[c] = __shfl_down(b[c], off, 64);
+        box_merge(b, o);
+    }
+    if (lane == 0) for (int c = 0; c < 6; ++c) sWave[wv][c] = b[c];
+    __syncthreads();
+    if (threadIdx.x == 0) for (int w = 1; w < BB_WAVES; ++w) box_merge(b, sWave[w]);
+}
+// thread 0 ends up with the leftmost extremum of the block's (value, position) pairs
+__device__ __forceinline__ void block_reduce_leftmost(bool isMin, float& v, int& p, float* sRedV, int* sRedP) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_down(v, off, 64); const int op = __shfl_down(p, off, 64);
+        if (takes_over(isMin, ov, op, v, p)) { v = ov; p = op; }
+    }
+    __syncthreads();
+    if (lane == 0) { sRedV[wv] = v; sRedP[wv] = p; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int w = 1; w < BB_WAVES; ++w) if (takes_over(isMin, sRedV[w], sRedP[w], v, p)) { v = sRedV[w]; p = sRedP[w]; }
+}
+__device__ __forceinline__ int block_sum(int v, int* sWaveI) {      // every thread gets the sum
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sWaveI[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int t = 0;
+    for (int w = 0; w < BB_WAVES; ++w) t += sWaveI[w];
+    return t;
+}
+
+__global__ __launch_bounds__(BB_THREADS) void bbL_setup(BlasBuild B, int srcBuf, int nLarge) {
+    __shared__ int sWaveI[BB_WAVES];
+    __shared__ int sCarry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) sCarry = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < nLarge; j0 += BB_THREADS) {
+        const int j = j0 + tid;
+        int cnt = 0;
+        if (j < nLarge) { const BuildNode nd = B.nodes[B.largeNodes[srcBuf][j]]; cnt = (nd.end - nd.start + BB_CHUNK - 1) / BB_CHUNK; }
+        int incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+        if (lane == 63) sWaveI[wv] = incl;
+        __syncthreads();
+        int before = sCarry + incl - cnt;
+        for (int w = 0; w < wv; ++w) before += sWaveI[w];
+        if (j < nLarge) B.nodeChunkBase[j] = before;
+        __syncthreads();
+        if (tid == BB_THREADS - 1) sCarry = before + cnt;
+        __syncthreads();
+    }
+    if (tid == 0) B.nodeChunkBase[nLarge] = sCarry;
+}
+
+// grid (chunks, 4): y < 3: box of the chunk along axis y;  y == 3: bounds partial of the chunk in idx order
+__global__ __launch_bounds__(BB_THREADS) void bbL_totals(BlasBuild B, int srcBuf, int nLarge) {
+    __shared__ float sWave[BB_WAVES][6];
+    __shared__ float sRedV[BB_WAVES];
+    __shared__ int sRedP[BB_WAVES];
+    int j, nodeId, start, N, cl;
+    const int c = blockIdx.x, a = blockIdx.y, tid = threadIdx.x;
+    if (!locate(B, srcBuf, nLarge, c, j, nodeId, start, N, cl)) return;
+    const int q0 = cl * BB_CHUNK;
+    if (a < 3) {
+        float b[6];
+        box_identity(b);
+        const int* ord = B.ord[srcBuf][a] + start;
+        for (int e = 0; e < BB_E; ++e) {
+            const int q = q0 + tid * BB_E + e;
+            if (q < N) { float t[6]; load_box(B, ord[q], t); box_merge(b, t); }
+        }
+        block_reduce_box(b, sWave);
+        if (tid == 0) for (int k = 0; k < 6; ++k) B.chunkBox[((size_t)a * B.maxC + c) * 6 + k] = b[k];
+    } else {
+        float bv[6]; int bp[6];
+        for (int k = 0; k < 6; ++k) { bv[k] = k < 3 ? BB_FMAX : -BB_FMAX; bp[k] = BB_NOPOS; }
+        for (int e = 0; e < BB_E; ++e) {
+            const int q = q0 + tid * BB_E + e;
+            if (q < N) {
+                float t[6];
+                load_box(B, B.idx[start + q], t);
+                for (int k = 0; k < 3; ++k) {
+                    if (t[k] < bv[k]) { bv[k] = t[k]; bp[k] = start + q; }
+                    if (bv[3 + k] < t[3 + k]) { bv[3 + k] = t[3 + k]; bp[3 + k] = start + q; }
+                }
+            }
+        }
+        for (int k = 0; k < 6; ++k) {
+            float v = bv[k]; int p = bp[k];
+            block_reduce_leftmost(k < 3, v, p, sRedV, sRedP);
+            if (tid == 0) { B.chunkBox[((size_t)3 * B.maxC + c) * 6 + k] = v; B.chunkPos[(size_t)c * 6 + k] = p; }
+        }
+    }
+}
+
+// grid (large nodes): node bounds from the partials; exclusive prefix / suffix boxes of the chunk totals per axis
+__global__ __launch_bounds__(BB_THREADS) void bbL_node(BlasBuild B, int srcBuf, int nLarge) {
+    __shared__ float sWave[BB_WAVES][6];
+    __shared__ float sRun[6];
+    __shared__ float sRedV[BB_WAVES];
+    __shared__ int sRedP[BB_WAVES];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int nodeId = B.largeNodes[srcBuf][j];
+    const int c0 = B.nodeChunkBase[j], C = B.nodeChunkBase[j + 1] - c0;
+    for (int k = 0; k < 6; ++k) {
+        const bool isMin = k < 3;
+        float v = isMin ? BB_FMAX : -BB_FMAX; int p = BB_NOPOS;
+        for (int cc = tid; cc < C; cc += BB_THREADS) {
+            const float ov = B.chunkBox[((size_t)3 * B.maxC + c0 + cc) * 6 + k]; const int op = B.chunkPos[(size_t)(c0 + cc) * 6 + k];
+            if (takes_over(isMin, ov, op, v, p)) { v = ov; p = op; }
+        }
+        block_reduce_leftmost(isMin, v, p, sRedV, sRedP);
+        if (tid == 0) { B.nodeBox[j * 6 + k] = v; if (isMin) B.nodes[nodeId].bmin[k] = v; else B.nodes[nodeId].bmax[k - 3] = v; }
+    }
+    for (int a = 0; a < 3; ++a) {
+        const float* tot = B.chunkBox + ((size_t)a * B.maxC + c0) * 6;
+        float* pre = B.chunkPre + ((size_t)a * B.maxC + c0) * 6;
+        float* suf = B.chunkSuf + ((size_t)a * B.maxC + c0) * 6;
+        for (int dir = 0; dir < 2; ++dir) {
+            __syncthreads();
+            if (tid < 6) sRun[tid] = tid < 3 ? BB_FMAX : -BB_FMAX;
+            __syncthreads();
+            for (int g0 = 0; g0 < C; g0 += BB_CHUNK) {
+                float loc[BB_E][6];
+                for (int e = 0; e < BB_E; ++e) {
+                    const int r = g0 + tid * BB_E + e;
+                    box_identity(loc[e]);
+                    if (r < C) { const int g = dir == 0 ? r : C - 1 - r; for (int k = 0; k < 6; ++k) loc[e][k] = tot[(size_t)g * 6 + k]; }
+                }
+                scan_chunk(loc, sWave, sRun);
+                for (int e = 0; e < BB_E; ++e) {
+                    const int r = g0 + tid * BB_E + e;
+                    if (r + 1 < C) {                           // inclusive up to r = exclusive for the next chunk in scan order
+                        const int g = dir == 0 ? r + 1 : C - 2 - r;
+                        float* dst = (dir == 0 ? pre : suf) + (size_t)g * 6;
+                        for (int k = 0; k < 6; ++k) dst[k] = loc[e][k];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (tid < 6) { pre[tid] = tid < 3 ? BB_FMAX : -BB_FMAX; suf[(size_t)(C - 1) * 6 + tid] = tid < 3 ? BB_FMAX : -BB_FMAX; }
+    }
+}
+
+// grid (chunks, 3): suffix-box areas of the chunk's positions (BVH.cpp:58-66)
+__global__ __launch_bounds__(BB_THREADS) void bbL_suffix(BlasBuild B, int srcBuf, int nLarge) {
+    __shared__ float sWave[BB_WAVES][6];
+    __shared__ float sRun[6];
+    int j, nodeId, start, N, cl;
+    const int c = blockIdx.x, a = blockIdx.y, tid = threadIdx.x;
+    if (!locate(B, srcBuf, nLarge, c, j, nodeId, start, N, cl)) return;
+    const int q0 = cl * BB_CHUNK, len = (N - q0 < BB_CHUNK) ? N - q0 : BB_CHUNK;
+    if (tid < 6) sRun[tid] = B.chunkSuf[((size_t)a * B.maxC + c) * 6 + tid];
+    __syncthreads();
+    const int* ord = B.ord[srcBuf][a] + start;
+    float loc[BB_E][6];
+    for (int e = 0; e < BB_E; ++e) {
+        const int r = tid * BB_E + e;
+        box_identity(loc[e]);
+        if (r < len) load_box(B, ord[q0 + len - 1 - r], loc[e]);
+    }
+    scan_chunk(loc, sWave, sRun);
+    for (int e = 0; e < BB_E; ++e) {
+        const int r = tid * BB_E + e;
+        if (r < len) B.rarea3[a][start + q0 + len - 1 - r] = area2(loc[e]);
+    }
+}
+
+// grid (chunks, 3): prefix boxes and the cost of every split inside the chunk (BVH.cpp:49-57, 68-83)
+__global__ __launch_bounds__(BB_THREADS) void bbL_cost(BlasBuild B, int srcBuf, int nLarge) {
+    __shared__ float sWave[BB_WAVES][6];
+    __shared__ float sRun[6];
+    __shared__ Best sBest[BB_WAVES];
+    int j, nodeId, start, N, cl;
+    const int c = blockIdx.x, a = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (!locate(B, srcBuf, nLarge, c, j, nodeId, start, N, cl)) return;
+    const int q0 = cl * BB_CHUNK, len = (N - q0 < BB_CHUNK) ? N - q0 : BB_CHUNK;
+    if (tid < 6) sRun[tid] = B.chunkPre[((size_t)a * B.maxC + c) * 6 + tid];
+    __syncthreads();
+    const int* ord = B.ord[srcBuf][a] + start;
+    float loc[BB_E][6];
+    for (int e = 0; e < BB_E; ++e) {
+        const int r = tid * BB_E + e;
+        box_identity(loc[e]);
+        if (r < len) load_box(B, ord[q0 + r], loc[e]);
+    }
+    scan_chunk(loc, sWave, sRun);
+    const float parentArea = area2(B.nodeBox + j * 6);
+    Best myBest{BB_FMAX, 3, BB_NOPOS};
+    for (int e = 0; e < BB_E; ++e) {
+        const int r = tid * BB_E + e, i = q0 + r + 1;
+        if (r < len && i < N) {
+            const float leftArea = area2(loc[e]);
+            const float rightArea = B.rarea3[a][start + i];
+            const float cost = (leftArea * (float)i + rightArea * (float)(N - i)) / (parentArea + 1e-6f);
+            const Best cand{cost, a, i};
+            if (cost < BB_FMAX && better(cand, myBest)) myBest = cand;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.cost = __shfl_down(myBest.cost, off, 64); o.axis = __shfl_down(myBest.axis, off, 64); o.i = __shfl_down(myBest.i, off, 64);
+        if (better(o, myBest)) myBest = o;
+    }
+    if (lane == 0) sBest[wv] = myBest;
+    __syncthreads();
+    if (tid == 0) {
+        Best win = sBest[0];
+        for (int w = 1; w < BB_WAVES; ++w) if (better(sBest[w], win)) win = sBest[w];
+        B.chunkBestCost[(size_t)a * B.maxC + c] = win.cost;
+        B.chunkBestAt[(size_t)a * B.maxC + c] = win.axis < 3 ? win.i : -1;
+    }
+}
+
+// grid (large nodes): the node's split = lexicographic minimum over its chunks; children
+__global__ __launch_bounds__(BB_THREADS) void bbL_pick(BlasBuild B, int srcBuf, int nLarge) {
+    __shared__ Best sBest[BB_WAVES];
+    const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nodeId = B.largeNodes[srcBuf][j];
+    const BuildNode nd = B.nodes[nodeId];
+    const int start = nd.start, end = nd.end, N = end - start;
+    const int c0 = B.nodeChunkBase[j], C = B.nodeChunkBase[j + 1] - c0;
+    Best myBest{BB_FMAX, 3, BB_NOPOS};
+    for (int k = tid; k < 3 * C; k += BB_THREADS) {
+        const int a = k / C, cc = k - a * C;
+        const int at = B.chunkBestAt[(size_t)a * B.maxC + c0 + cc];
+        if (at >= 0) { const Best cand{B.chunkBestCost[(size_t)a * B.maxC + c0 + cc], a, at}; if (better(cand, myBest)) myBest = cand; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.cost = __shfl_down(myBest.cost, off, 64); o.axis = __shfl_down(myBest.axis, off, 64); o.i = __shfl_down(myBest.i, off, 64);
+        if (better(o, myBest)) myBest = o;
+    }
+    if (lane == 0) sBest[wv] = myBest;
+    __syncthreads();
+    if (tid != 0) return;
+    Best win = sBest[0];
+    for (int w = 1; w < BB_WAVES; ++w) if (better(sBest[w], win)) win = sBest[w];
+    int mid, used = 0;
+    if (win.axis < 3 && win.i > 0 && win.i < N) { mid = start + win.i; used = 1; }
+    else {          // BVH.cpp:135-149, sequential
+        const float* box = B.nodeBox + j * 6;
+        int axis = 0;
+        const float ex = box[3] - box[0], ey = box[4] - box[1], ez = box[5] - box[2];
+        if (ey > ex && ey > ez) axis = 1; else if (ez > ex) axis = 2;
+        const float split = 0.5f * (box[axis] + box[3 + axis]);
+        int m = start;
+        for (int p = start; p < end; ++p) {
+            if (B.cen[3 * B.idx[p] + axis] < split) { const int t = B.idx[p]; B.idx[p] = B.idx[m]; B.idx[m] = t; ++m; }
+        }
+        if (m == start || m == end) m = start + (N / 2);
+        for (int p = start; p < end; ++p) B.side[B.idx[p]] = (unsigned char)(p < m);
+        mid = m;
+    }
+    B.nodePick[j * 4 + 0] = win.axis; B.nodePick[j * 4 + 1] = win.i; B.nodePick[j * 4 + 2] = mid; B.nodePick[j * 4 + 3] = used;
+    push_children(B, srcBuf, nodeId, start, mid, end, nd.depth);
+}
+
+// grid (chunks): BVH.cpp:128-133 -- the index range becomes the best axis' order; side flags
+__global__ __launch_bounds__(BB_THREADS) void bbL_mark(BlasBuild B, int srcBuf, int nLarge) {
+    int j, nodeId, start, N, cl;
+    const int c = blockIdx.x, tid = threadIdx.x;
+    if (!locate(B, srcBuf, nLarge, c, j, nodeId, start, N, cl)) return;
+    if (!B.nodePick[j * 4 + 3]) return;
+    const int axis = B.nodePick[j * 4 + 0], split = B.nodePick[j * 4 + 1];
+    const int* ord = B.ord[srcBuf][axis] + start;
+    for (int e = 0; e < BB_E; ++e) {
+        const int q = cl * BB_CHUNK + e * BB_THREADS + tid;          // coalesced: order inside the chunk does not matter here
+        if (q < N) { const int id = ord[q]; B.idx[start + q] = id; B.side[id] = (unsigned char)(q < split); }
+    }
+}
+
+// grid (chunks, 3): how many of the chunk's elements go left
+__global__ __launch_bounds__(BB_THREADS) void bbL_count(BlasBuild B, int srcBuf, int nLarge) {
+    __shared__ int sWaveI[BB_WAVES];
+    int j, nodeId, start, N, cl;
+    const int c = blockIdx.x, a = blockIdx.y, tid = threadIdx.x;
+    if (!locate(B, srcBuf, nLarge, c, j, nodeId, start, N, cl)) return;
+    const int* ord = B.ord[srcBuf][a] + start;
+    int cnt = 0;
+    for (int e = 0; e < BB_E; ++e) {
+        const int q = cl * BB_CHUNK + e * BB_THREADS + tid;
+        if (q < N) cnt += B.side[ord[q]] ? 1 : 0;
+    }
+    cnt = block_sum(cnt, sWaveI);
+    if (tid == 0) B.chunkLefts[(size_t)a * B.maxC + c] = cnt;
+}
+
+// grid (chunks, 3): stable partition of the chunk into the children's ranges
+__global__ __launch_bounds__(BB_THREADS) void bbL_scatter(BlasBuild B, int srcBuf, int nLarge) {
+    __shared__ int sWaveI[BB_WAVES];
+    int j, nodeId, start, N, cl;
+    const int c = blockIdx.x, a = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (!locate(B, srcBuf, nLarge, c, j, nodeId, start, N, cl)) return;
+    int part = 0;
+    for (int cc = tid; cc < cl; cc += BB_THREADS) part += B.chunkLefts[(size_t)a * B.maxC + (c - cl) + cc];
+    const int carry = block_sum(part, sWaveI);                  // lefts in the node's earlier chunks
+    __syncthreads();
+    const int nLeft = B.nodePick[j * 4 + 2] - start;
+    const int* in = B.ord[srcBuf][a] + start;
+    int* out = B.ord[srcBuf ^ 1][a] + start;
+    const int q0 = cl * BB_CHUNK;
+    int ids[BB_E]; int flag[BB_E];
+    int cnt = 0;
+    for (int e = 0; e < BB_E; ++e) { const int q = q0 + tid * BB_E + e; ids[e] = q < N ? in[q] : -1; }
+    for (int e = 0; e < BB_E; ++e) { flag[e] = (ids[e] >= 0 && B.side[ids[e]]) ? 1 : 0; cnt += flag[e]; }
+    int incl = cnt;
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+    if (lane == 63) sWaveI[wv] = incl;
+    __syncthreads();
+    int before = carry + incl - cnt;
+    for (int w = 0; w < wv; ++w) before += sWaveI[w];
+    for (int e = 0; e < BB_E; ++e) {
+        const int q = q0 + tid * BB_E + e;
+        if (q < N) {
+            if (flag[e]) out[before] = ids[e];
+            else out[nLeft + (q - before)] = ids[e];
+            before += flag[e];
+        }
+    }
+}
+
 // ---- 4. numbering.  bottom-up: internal-node counts; top-down: reference indices.
 __global__ void bb_count_internals(BlasBuild B, int nNodes, int depth) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -520,6 +876,10 @@ size_t blas_build_workspace_bytes(size_t n) {
     b += up256(N * 4) + up256(N) + up256(N * 4);
     b += up256(M * sizeof(BuildNode));
     b += 6 * up256(M * 4);
+    const size_t ML = N / BB_LARGE + 2, MC = N / BB_CHUNK + ML + 2;
+    b += 3 * up256((ML + 1) * 4) + up256(ML * 24) + up256(ML * 16);
+    b += up256(4 * MC * 24) + up256(MC * 24) + 2 * up256(3 * MC * 24) + 3 * up256(3 * MC * 4);
+    b += 2 * up256(N * 4);
     b += up256(M * sizeof(rz_bvh_node));
     b += 256;
     return b;
@@ -547,9 +907,20 @@ int blas_build_device(const rz_triangle* hostTris, size_t n, void* workspace, si
     B.idx = reinterpret_cast<int*>(carve(N * 4));
     B.side = reinterpret_cast<unsigned char*>(carve(N));
     B.rarea = reinterpret_cast<float*>(carve(N * 4));
+    B.rarea3[0] = B.rarea;
     B.nodes = reinterpret_cast<BuildNode*>(carve(M * sizeof(BuildNode)));
     B.levelNodes[0] = reinterpret_cast<int*>(carve(M * 4)); B.levelNodes[1] = reinterpret_cast<int*>(carve(M * 4));
     B.smallNodes[0] = reinterpret_cast<int*>(carve(M * 4)); B.smallNodes[1] = reinterpret_cast<int*>(carve(M * 4));
+    const size_t ML = N / BB_LARGE + 2, MC = N / BB_CHUNK + ML + 2;
+    B.maxC = (int)MC;
+    B.largeNodes[0] = reinterpret_cast<int*>(carve((ML + 1) * 4)); B.largeNodes[1] = reinterpret_cast<int*>(carve((ML + 1) * 4));
+    B.nodeChunkBase = reinterpret_cast<int*>(carve((ML + 1) * 4));
+    B.nodeBox = reinterpret_cast<float*>(carve(ML * 24)); B.nodePick = reinterpret_cast<int*>(carve(ML * 16));
+    B.chunkBox = reinterpret_cast<float*>(carve(4 * MC * 24)); B.chunkPos = reinterpret_cast<int*>(carve(MC * 24));
+    B.chunkPre = reinterpret_cast<float*>(carve(3 * MC * 24)); B.chunkSuf = reinterpret_cast<float*>(carve(3 * MC * 24));
+    B.chunkBestCost = reinterpret_cast<float*>(carve(3 * MC * 4)); B.chunkBestAt = reinterpret_cast<int*>(carve(3 * MC * 4));
+    B.chunkLefts = reinterpret_cast<int*>(carve(3 * MC * 4));
+    B.rarea3[1] = reinterpret_cast<float*>(carve(N * 4)); B.rarea3[2] = reinterpret_cast<float*>(carve(N * 4));
     int* rank = reinterpret_cast<int*>(carve(M * 4));
     int* refIdx = reinterpret_cast<int*>(carve(M * 4));
     B.outNodes = reinterpret_cast<rz_bvh_node*>(carve(M * sizeof(rz_bvh_node)));
@@ -570,17 +941,30 @@ int blas_build_device(const rz_triangle* hostTris, size_t n, void* workspace, si
         hipLaunchKernelGGL(bb_take_ids, dim3(blocks), dim3(256), 0, s, B, a);
     }
     hipLaunchKernelGGL(bb_init_root, dim3(1), dim3(1), 0, s, B);
-    int bigCount = n > (size_t)BB_SMALL ? 1 : 0, smallCount = 1 - bigCount, buf = 0, hostCounters[4] = {1, 0, 1, 0}, levels = 0;
-    while (bigCount > 0 || smallCount > 0) {
+    int largeCount = n > (size_t)BB_LARGE ? 1 : 0, smallCount = n <= (size_t)BB_SMALL ? 1 : 0, bigCount = 1 - largeCount - smallCount;
+    int buf = 0, hostCounters[8] = {0}, levels = 0;
+    while (largeCount > 0 || bigCount > 0 || smallCount > 0) {
         if (++levels > 4096) { (void)hipFree(temp); return -1; }
+        if (largeCount > 0) {
+            const unsigned g = (unsigned)(N / BB_CHUNK) + (unsigned)largeCount;       // >= sum of ceil(N_j / chunk)
+            const dim3 T(BB_THREADS);
+            hipLaunchKernelGGL(bbL_setup, dim3(1), T, 0, s, B, buf, largeCount);
+            hipLaunchKernelGGL(bbL_totals, dim3(g, 4), T, 0, s, B, buf, largeCount);
+            hipLaunchKernelGGL(bbL_node, dim3(largeCount), T, 0, s, B, buf, largeCount);
+            hipLaunchKernelGGL(bbL_suffix, dim3(g, 3), T, 0, s, B, buf, largeCount);
+            hipLaunchKernelGGL(bbL_cost, dim3(g, 3), T, 0, s, B, buf, largeCount);
+            hipLaunchKernelGGL(bbL_pick, dim3(largeCount), T, 0, s, B, buf, largeCount);
+            hipLaunchKernelGGL(bbL_mark, dim3(g), T, 0, s, B, buf, largeCount);
+            hipLaunchKernelGGL(bbL_count, dim3(g, 3), T, 0, s, B, buf, largeCount);
+            hipLaunchKernelGGL(bbL_scatter, dim3(g, 3), T, 0, s, B, buf, largeCount);
+        }
         if (bigCount > 0) hipLaunchKernelGGL(bb_level, dim3(bigCount), dim3(BB_THREADS), 0, s, B, buf, bigCount);
         if (smallCount > 0)
             hipLaunchKernelGGL(bb_level_small, dim3((smallCount + BB_SMALL_WAVES - 1) / BB_SMALL_WAVES), dim3(BB_SMALL_THREADS), 0, s, B, buf, smallCount);
-        BB_HIP(hipMemcpyAsync(hostCounters, B.counters, 16, hipMemcpyDeviceToHost, s));
+        BB_HIP(hipMemcpyAsync(hostCounters, B.counters, 32, hipMemcpyDeviceToHost, s));
         BB_HIP(hipStreamSynchronize(s));
-        bigCount = hostCounters[1]; smallCount = hostCounters[3];
-        BB_HIP(hipMemsetAsync(B.counters + 1, 0, 4, s));
-        BB_HIP(hipMemsetAsync(B.counters + 3, 0, 4, s));
+        bigCount = hostCounters[1]; smallCount = hostCounters[3]; largeCount = hostCounters[4];
+        BB_HIP(hipMemsetAsync(B.counters + 1, 0, 16, s));
         buf ^= 1;
     }
     const int nNodes = hostCounters[0], depth = levels;      // every level of the loop produced nodes of that depth

@@ -13,6 +13,7 @@
 // The POD element types ARE the C-ABI structs of include/rayzen_hip.h
 // (static_asserted below), i.e. the SSBO byte layouts of the reference.
 #pragma once
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -165,8 +166,13 @@ struct SceneBuffers {
     // shareMeshes = false reproduces the reference exactly (one BLAS copy and
     // one triangle copy per GameObject, main.cpp:951-1007); true stores one
     // BLAS per distinct Mesh and points every instance of it at that copy.
-    void build(const Scene& scene, bool shareMeshes = false);
+    // false only when `blasBuilder` is set and fails (nothing is built then; the host builder is NOT used instead).
+    bool build(const Scene& scene, bool shareMeshes = false);
     void updateDynamic(const Scene& scene);
+
+    // Optional replacement for BVH::buildBLAS, e.g. rz_build_blas of include/rayzen_hip.h bound to a context (the
+    // device builder, byte-identical output).  Fills `out.nodes` / `out.triIndices`; returns false on failure.
+    std::function<bool(const Mesh& mesh, BVH& out)> blasBuilder;
 };
 
 // World AABB of a BLAS root under a transform (main.cpp:974-993).

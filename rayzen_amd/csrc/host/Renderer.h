@@ -27,8 +27,24 @@ public:
     Renderer(const Renderer&) = delete;
     Renderer& operator=(const Renderer&) = delete;
 
+    // Build every BLAS on the device (rz_build_blas: RayZen's full-sweep SAH, same bytes as BVH::buildBLAS).
+    void useDeviceBlasBuilder(bool on = true) {
+        if (!on) { buffers_.blasBuilder = nullptr; return; }
+        buffers_.blasBuilder = [this](const Mesh& mesh, BVH& out) {
+            const size_t n = mesh.triangles.size();
+            out.nodes.assign(n ? 2 * n - 1 : 1, BVHNode{});
+            out.triIndices.assign(n, 0);
+            size_t nn = 0;
+            if (rz_build_blas(ctx_, reinterpret_cast<const rz_triangle*>(mesh.triangles.data()), n,
+                              reinterpret_cast<rz_bvh_node*>(out.nodes.data()), out.nodes.size(), out.triIndices.data(), &nn,
+                              nullptr, nullptr) != RZ_OK) return false;
+            out.nodes.resize(nn);
+            return true;
+        };
+    }
+
     void initializeSSBOs(const Scene& scene, bool shareMeshes = false) {
-        buffers_.build(scene, shareMeshes);
+        if (!buffers_.build(scene, shareMeshes)) throw std::runtime_error(std::string("rz_build_blas: ") + rz_last_error(ctx_));
         up(RZ_BIND_TRIANGLES, buffers_.allTriangles);
         up(RZ_BIND_MATERIALS, scene.materials);
         up(RZ_BIND_LIGHTS, scene.lights);

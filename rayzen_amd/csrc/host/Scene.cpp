@@ -42,7 +42,7 @@ BVHNode worldRootNode(const BVHNode& meshRoot, const mat4& transform) {
     return r;
 }
 
-void SceneBuffers::build(const Scene& scene, bool shareMeshes) {
+bool SceneBuffers::build(const Scene& scene, bool shareMeshes) {
     allTriangles.clear(); allBLASNodes.clear(); allBLASTriIndices.clear();
     meshInstances.clear(); tlasNodes.clear(); tlasTriIndices.clear(); blasRoots.clear();
     maxBLASDepth = 1;
@@ -61,7 +61,8 @@ void SceneBuffers::build(const Scene& scene, bool shareMeshes) {
         auto it = built.find(mesh);
         if (it == built.end()) {
             it = built.emplace(mesh, BVH{}).first;
-            it->second.buildBLAS(mesh->triangles);
+            if (blasBuilder) { if (!blasBuilder(*mesh, it->second)) return false; }
+            else it->second.buildBLAS(mesh->triangles);
             maxBLASDepth = std::max(maxBLASDepth, it->second.depth());
         }
         const BVH& blas = it->second;
@@ -95,6 +96,7 @@ void SceneBuffers::build(const Scene& scene, bool shareMeshes) {
     tlasNodes = tlas.nodes;
     tlasTriIndices = tlas.triIndices;
     tlasDepth = tlas.depth();
+    return true;
 }
 
 void SceneBuffers::updateDynamic(const Scene& scene) {

@@ -96,8 +96,24 @@ int rzh_scene_set_transform(rzh_scene* s, int object_id, const float transform[1
 
 int rzh_scene_build(rzh_scene* s, int share_meshes) {
     if (!s) return -1;
-    s->buffers.build(s->scene, share_meshes != 0);
-    s->built = true;
+    s->built = s->buffers.build(s->scene, share_meshes != 0);
+    return s->built ? 0 : -2;
+}
+
+int rzh_scene_set_blas_builder(rzh_scene* s, rzh_blas_builder_fn fn, void* ctx) {
+    if (!s) return -1;
+    if (!fn) { s->buffers.blasBuilder = nullptr; return 0; }
+    s->buffers.blasBuilder = [fn, ctx](const Mesh& mesh, BVH& out) {
+        const size_t n = mesh.triangles.size();
+        out.nodes.assign(n ? 2 * n - 1 : 1, BVHNode{});
+        out.triIndices.assign(n, 0);
+        size_t nn = 0;
+        const int rc = fn(ctx, reinterpret_cast<const rz_triangle*>(mesh.triangles.data()), n,
+                          reinterpret_cast<rz_bvh_node*>(out.nodes.data()), out.nodes.size(), out.triIndices.data(), &nn, nullptr, nullptr);
+        if (rc != 0 || nn == 0 || nn > out.nodes.size()) return false;
+        out.nodes.resize(nn);
+        return true;
+    };
     return 0;
 }
 

@@ -233,8 +233,21 @@ class Scene:
         L.rzh_scene_depths(self._h, C.byref(bd), C.byref(td))
         self.max_blas_depth, self.tlas_depth = bd.value, td.value
 
+    def set_blas_builder(self, renderer):
+        """Build every BLAS of build() with renderer's device builder (rz_build_blas; same bytes as the host builder).
+        None restores the host builder.  The renderer must outlive the scene's build() calls."""
+        if renderer is None:
+            fn, ctx = None, None
+        else:
+            fn, ctx = C.cast(renderer._L.rz_build_blas, C.c_void_p), renderer._c
+        if _lib.host().rzh_scene_set_blas_builder(self._h, fn, ctx) != 0:
+            raise RuntimeError("rzh_scene_set_blas_builder failed")
+
     def build(self, share_meshes=False):
-        if _lib.host().rzh_scene_build(self._h, 1 if share_meshes else 0) != 0:
+        rc = _lib.host().rzh_scene_build(self._h, 1 if share_meshes else 0)
+        if rc == -2:
+            raise RuntimeError("rzh_scene_build: the device BLAS builder failed")
+        if rc != 0:
             raise RuntimeError("rzh_scene_build failed")
         self._pull(GEOMETRY_BINDINGS)
         return self
@@ -279,7 +292,7 @@ def cornell_scene():
     return s.build()
 
 
-def bunny_scene(n=76, aspect=16.0 / 9.0, bunny_material=0, floor_material=4, extras=False, radius=2.8):
+def bunny_scene(n=76, aspect=16.0 / 9.0, bunny_material=0, floor_material=4, extras=False, radius=2.8, blas_builder=None):
     """C2/C3: ~69k-triangle closed mesh ('bunny' stand-in, 12*n*n triangles) over the reference's floor.
 
     extras adds a glass blob and a mirror cube so every material branch is exercised."""
@@ -295,6 +308,7 @@ def bunny_scene(n=76, aspect=16.0 / 9.0, bunny_material=0, floor_material=4, ext
         s.add_object(glass, translate(identity(), (4.5, 0.6, 3.0)))
         s.add_object(mirror, rotate(translate(identity(), (-5.0, 0.0, 1.5)), 0.5, (0.0, 1.0, 0.0)))
     s.name = f"bunny{12 * n * n}" + ("+glass+mirror" if extras else "")
+    s.set_blas_builder(blas_builder)        # a Renderer: BLAS built on the device (same bytes); None: host builder
     return s.build()
 
 
@@ -321,7 +335,7 @@ def instanced_scene(n=76, count=16, aspect=16.0 / 9.0, share_meshes=True):
     return s.build(share_meshes=share_meshes)
 
 
-def stress_scene(n=289, aspect=16.0 / 9.0):
+def stress_scene(n=289, aspect=16.0 / 9.0, blas_builder=None):
     """C5: ~1M-triangle blob, radius 10."""
     s = Scene(camera=Camera(position=(0.0, 6.0, 34.0), aspect=aspect))
     floor = s.add_mesh(make_cube(4))
@@ -329,4 +343,5 @@ def stress_scene(n=289, aspect=16.0 / 9.0):
     s.add_object(floor, translate(scale(identity(), (40.0, 0.5, 40.0)), (0.0, -28.0, 0.0)))
     s.add_object(blob, identity())
     s.name = f"stress{12 * n * n}"
+    s.set_blas_builder(blas_builder)
     return s.build()

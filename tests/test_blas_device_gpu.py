@@ -97,3 +97,15 @@ def test_a_larger_mesh_and_the_scene_built_from_it_renders_identically(r):
     t = S.make_blob(150, 1.0, 0)               # 270 000 triangles
     nodes, idx, ms = check(r, t, oracle=False)
     assert ms > 0
+
+
+def test_scene_build_with_the_device_builder_gives_the_same_buffers(r):
+    host = S.bunny_scene(n=20, extras=True)
+    dev = S.bunny_scene(n=20, extras=True, blas_builder=r)
+    for b in S.GEOMETRY_BINDINGS:
+        assert dev.arrays[b].tobytes() == host.arrays[b].tobytes(), b
+    assert (dev.max_blas_depth, dev.tlas_depth) == (host.max_blas_depth, host.tlas_depth)
+    dev.set_blas_builder(None)              # back to the host builder: still the same
+    dev.build()
+    for b in S.GEOMETRY_BINDINGS:
+        assert dev.arrays[b].tobytes() == host.arrays[b].tobytes(), b
