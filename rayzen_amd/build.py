@@ -23,8 +23,11 @@ HIP_SO = os.path.join(LIB, "librayzen_hip.so")
 HOST_SO = os.path.join(LIB, "librayzen_host.so")
 
 # -ffp-contract=off is part of the numerics contract (rz_device_math.h), not a tuning flag.
+# -fno-slp-vectorize: left on, the SLP vectoriser pairs neighbouring f32 adds/multiplies into v_pk_*_f32 on 64-bit
+# register tuples; in the render kernel that cost 25 VGPRs (167 vs 142) for no gain in issue slots.  Where packed math
+# does pay (the two-plane slab test) it is written explicitly (rz_trace.h).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-               "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+               "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra"]
 
 

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -224,8 +225,10 @@ int build_view(rz_ctx* c, int nodeOff, int triOff, int gTriOff, BlasView& V) {
             DevPair P{};
             const rz_bvh_node& ln = nodes[nodeOff + L];
             const rz_bvh_node& rn = nodes[nodeOff + R];
-            std::memcpy(P.lmin, ln.boundsMin, 12); std::memcpy(P.lmax, ln.boundsMax, 12);
-            std::memcpy(P.rmin, rn.boundsMin, 12); std::memcpy(P.rmax, rn.boundsMax, 12);
+            P.lx[0] = ln.boundsMin[0]; P.lx[1] = ln.boundsMax[0]; P.ly[0] = ln.boundsMin[1]; P.ly[1] = ln.boundsMax[1];
+            P.lz[0] = ln.boundsMin[2]; P.lz[1] = ln.boundsMax[2];
+            P.rx[0] = rn.boundsMin[0]; P.rx[1] = rn.boundsMax[0]; P.ry[0] = rn.boundsMin[1]; P.ry[1] = rn.boundsMax[1];
+            P.rz[0] = rn.boundsMin[2]; P.rz[1] = rn.boundsMax[2];
             V.depth = std::max(V.depth, it.depth + 1);
             const rz_bvh_node* ch[2] = {&ln, &rn};
             int32_t* encs[2] = {&P.lenc, &P.renc};
@@ -505,6 +508,10 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     K.materials = static_cast<const DevMaterial*>(c->dMat.p);
     K.lights = static_cast<const DevLight*>(c->dLight.p);
     K.accum = accum;
+    if (std::getenv("RZ_DEBUG_PTRS")) {
+        static int once = 0;
+        if (once++ < 64) std::fprintf(stderr, "rz ptrs: pairs %p tris %p inst %p tlasN %p tlasI %p mat %p light %p accum %p\n", (void*)K.pairs, (void*)K.tris, (void*)K.instances, (void*)K.tlasNodes, (void*)K.tlasIndices, (void*)K.materials, (void*)K.lights, (void*)K.accum);
+    }
     K.ior = static_cast<float*>(c->dIor.p);
     K.nTlasNodes = c->deviceOwnsTlas ? c->devTlasNodes : (int)hostCount<rz_bvh_node>(c, RZ_BIND_TLAS_NODES);
     K.nLights = std::max(0, std::min<int>(f.num_lights, (int)hostCount<rz_light>(c, RZ_BIND_LIGHTS)));

@@ -146,8 +146,16 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
 //   * each lane runs one sample's path and parks its two addends in LDS (2 KB per wave); one lane per pixel then
 //     replays `color += light; color += sky` in sample order, so the sum is bit-identical to the shader's.
 //     Nothing but the final pixel value goes to HBM.
+// Waves per SIMD asked of the compiler (the kernel is issue-bound: another resident wave overlaps scalar / VMEM / LDS
+// issue with VALU).  Measured on C2: 2 -> 29.0 ms, 3 -> 22.1 ms; 4 paid off only once the SLP vectoriser was switched
+// off (build.py: it paired f32 ops into 64-bit register tuples and cost 25 VGPRs): 142 VGPRs -> 128 with 13 spilled,
+// 18.65 -> 17.65 ms.  The transparent variant keeps 3: its 13.6 KB of LDS per wave caps occupancy first, and at 128
+// VGPRs it spills 28 (measured 49.4 -> 54.3 ms at 4).
 #ifndef RZ_SAMPLES_MIN_WAVES
-#define RZ_SAMPLES_MIN_WAVES 3   // measured on C2: 2 -> 29.0 ms, 3 -> 22.1 ms, 4 -> 22.1 ms (the kernel is issue-bound; a third wave overlaps scalar/VMEM/LDS issue with VALU)
+#define RZ_SAMPLES_MIN_WAVES 4
+#endif
+#ifndef RZ_SAMPLES_MIN_WAVES_GLASS
+#define RZ_SAMPLES_MIN_WAVES_GLASS 3
 #endif
 __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
     a.traversals += b.traversals; a.tlas_nodes += b.tlas_nodes; a.tlas_leaf_indices += b.tlas_leaf_indices;
@@ -159,7 +167,7 @@ __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
 }
 
 template <bool COUNT, bool GLASS>
-__global__ __launch_bounds__(64, RZ_SAMPLES_MIN_WAVES) void rz_render_samples(const KParams K) {
+__global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES_MIN_WAVES) void rz_render_samples(const KParams K) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     uint2* bstk = reinterpret_cast<uint2*>(lds_raw) + lane;

@@ -13,7 +13,9 @@
 //    children as adjacent pairs (BVH.cpp:166-171) and its shader fetches them
 //    separately when popped; here one aligned 64-B record (4 x dwordx4 per
 //    lane, one cache line) serves both box tests at the moment the parent is
-//    expanded.
+//    expanded.  The two planes of an axis sit side by side so that
+//    (plane - o) * inv runs as v_pk_add_f32 / v_pk_mul_f32 on the pair (same
+//    IEEE operations, half the issue slots; rz_trace.h: slab_pair).
 //  * enc: >= 0  -> internal child: index of ITS DevPair (relative to the
 //                  BLAS's pair base);
 //         <  0  -> leaf child: ~enc = (firstSlot << 4) | count, count 0..15,
@@ -32,11 +34,12 @@
 
 namespace rz {
 
-struct alignas(64) DevPair {
-    float lmin[3]; int32_t lenc;
-    float lmax[3]; int32_t lpad;
-    float rmin[3]; int32_t renc;
-    float rmax[3]; int32_t rpad;
+struct alignas(64) DevPair {     // per axis (min, max) adjacent: one packed-f32 op handles both planes of an axis
+    float lx[2], ly[2];          // left child's box
+    float lz[2], rx[2];          // ... and the right child's
+    float ry[2], rz[2];
+    int32_t lenc, renc;
+    int32_t pad[2];
 };
 static_assert(sizeof(DevPair) == 64, "DevPair is one 64-B line");
 

@@ -90,6 +90,42 @@ __device__ __forceinline__ bool slab(v3 o, v3 inv, float bx0, float by0, float b
     return tmax >= fmax_(tmin, 0.0f);
 }
 
+// The same test for the two children of a DevPair, with the subtractions and multiplications of an axis' two planes
+// issued as packed FP32 (v_pk_add_f32 with the origin negated, v_pk_mul_f32): the identical IEEE operations on the
+// identical operands, two per issue slot.  The origin and the reciprocal direction are broadcast to both halves by
+// op_sel, so they stay in the registers they already occupy.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct RayPk { f32x2 oxy, ozz, ixy, izz; };          // (o.x, o.y) (o.z, o.z) (inv.x, inv.y) (inv.z, inv.z)
+__device__ __forceinline__ RayPk make_raypk(v3 o, v3 inv) {
+    RayPk r;
+    r.oxy = f32x2{o.x, o.y}; r.ozz = f32x2{o.z, o.z}; r.ixy = f32x2{inv.x, inv.y}; r.izz = f32x2{inv.z, inv.z};
+    return r;
+}
+// (written as 2-vector IR, not inline asm: the compiler folds the broadcast into op_sel itself, and it then knows the
+// products are canonical, so the min/max that follow need no v_max(x, x) quieting first)
+#define RZ_PLANES(out, C, box, o2, i2, SEL)                                                                          \
+    do {                                                                                                             \
+        const f32x2 ob_ = __builtin_shufflevector(o2, o2, SEL, SEL), ib_ = __builtin_shufflevector(i2, i2, SEL, SEL);\
+        out = ((box) - ob_) * ib_;                                                                                   \
+    } while (0)
+__device__ __forceinline__ bool slab_finish(f32x2 tx, f32x2 ty, f32x2 tz, float& tmin) {
+    const float sx = fmin_(tx.x, tx.y), sy = fmin_(ty.x, ty.y), sz = fmin_(tz.x, tz.y);
+    const float gx = fmax_(tx.x, tx.y), gy = fmax_(ty.x, ty.y), gz = fmax_(tz.x, tz.y);
+    tmin = fmax_(fmax_(sx, sy), sz);
+    const float tmax = fmin_(fmin_(gx, gy), gz);
+    return tmax >= fmax_(tmin, 0.0f);
+}
+#define RZ_SLAB_PAIR(C, R, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr)                                                   \
+    do {                                                                                                             \
+        f32x2 ax_, ay_, az_, bx_, by_, bz_;                                                                          \
+        RZ_PLANES(ax_, C, lx, (R).oxy, (R).ixy, 0); RZ_PLANES(ay_, C, ly, (R).oxy, (R).ixy, 1);                      \
+        RZ_PLANES(az_, C, lz, (R).ozz, (R).izz, 0);                                                                  \
+        RZ_PLANES(bx_, C, rx, (R).oxy, (R).ixy, 0); RZ_PLANES(by_, C, ry, (R).oxy, (R).ixy, 1);                      \
+        RZ_PLANES(bz_, C, rz, (R).ozz, (R).izz, 0);                                                                  \
+        hl = slab_finish(ax_, ay_, az_, tl);                                                                         \
+        hr = slab_finish(bx_, by_, bz_, tr);                                                                         \
+    } while (0)
+
 // FS:391-416 without the outputs that are pure functions of (ray, t, triangle).
 // Evaluated without early exits: the accept decision is the conjunction of the
 // shader's tests in order, so values computed past a failed test are never used.
@@ -155,6 +191,7 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
     int sp = 0;
     const DevPair* __restrict__ pairs = K.pairs + I->pairBase;
     const DevTri* __restrict__ tris = K.tris + I->triBase;
+    const RayPk RP = make_raypk(lo, inv);
     // "while-while": the inner loop walks internal nodes; a lane that reaches a leaf parks there (its own
     // sequence of operations is unchanged) until the lanes of the wave still descending are few, then the
     // parked lanes test their leaves together.  Without this the wave ran the triangle tests for ~7 of its
@@ -174,20 +211,22 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
             if (__ballot(pp != upp) == 0ull) {       // every active lane wants the same pair: one scalar fetch,
                 RZ_SITE(c, 7);                        // box values consumed straight from SGPRs
                 const f32x16 q = sload16(upp);
-                hl = slab(lo, inv, q[0], q[1], q[2], q[4], q[5], q[6], tl);
-                hr = slab(lo, inv, q[8], q[9], q[10], q[12], q[13], q[14], tr);
-                lenc = __float_as_int(q[3]);
-                renc = __float_as_int(q[11]);
+                const f32x2 lx = {q[0], q[1]}, ly = {q[2], q[3]}, lz = {q[4], q[5]};
+                const f32x2 rx = {q[6], q[7]}, ry = {q[8], q[9]}, rz = {q[10], q[11]};
+                RZ_SLAB_PAIR("s", RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
+                lenc = __float_as_int(q[12]);
+                renc = __float_as_int(q[13]);
             } else
 #endif
             {
                 const float4* __restrict__ p4 = reinterpret_cast<const float4*>(pp);
                 float4 p0 = p4[0], p1 = p4[1], p2 = p4[2], p3 = p4[3];
-                RZ_KEEP4(p0); RZ_KEEP4(p2);
-                hl = slab(lo, inv, p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, tl);
-                hr = slab(lo, inv, p2.x, p2.y, p2.z, p3.x, p3.y, p3.z, tr);
-                lenc = __float_as_int(p0.w);
-                renc = __float_as_int(p2.w);
+                RZ_KEEP4(p0); RZ_KEEP4(p3);
+                const f32x2 lx = {p0.x, p0.y}, ly = {p0.z, p0.w}, lz = {p1.x, p1.y};
+                const f32x2 rx = {p1.z, p1.w}, ry = {p2.x, p2.y}, rz = {p2.z, p2.w};
+                RZ_SLAB_PAIR("v", RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
+                lenc = __float_as_int(p3.x);
+                renc = __float_as_int(p3.y);
             }
             if (hl) {
                 bstk[sp * 64] = make_uint2((unsigned)lenc, __float_as_uint(tl));

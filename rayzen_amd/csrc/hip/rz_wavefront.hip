@@ -272,14 +272,17 @@ __global__ __launch_bounds__(256) void wf_trace(const KParams K, const WFParams 
                 const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
                 if (COUNT) c.blas_nodes += 2;
                 float tl, tr;
-                const bool hl = slab(lo, linv, p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, tl);
-                const bool hr = slab(lo, linv, p2.x, p2.y, p2.z, p3.x, p3.y, p3.z, tr);
+                bool hl, hr;
+                const RayPk RP = make_raypk(lo, linv);
+                const f32x2 lx = {p0.x, p0.y}, ly = {p0.z, p0.w}, lz = {p1.x, p1.y};
+                const f32x2 rx = {p1.z, p1.w}, ry = {p2.x, p2.y}, rz = {p2.z, p2.w};
+                RZ_SLAB_PAIR("v", RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
                 if (hl) {
-                    bstk[sp * 64] = make_uint2((unsigned)__float_as_int(p0.w), __float_as_uint(tl));
+                    bstk[sp * 64] = make_uint2((unsigned)__float_as_int(p3.x), __float_as_uint(tl));
                     ++sp;
                 }
                 if (hr && !(tr > tLoc)) {
-                    cur = __float_as_int(p2.w);
+                    cur = __float_as_int(p3.y);
                 } else {
                     finished = true;
                     while (sp > 0) {
