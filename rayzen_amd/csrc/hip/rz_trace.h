@@ -206,8 +206,11 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
             int lenc, renc;
 #if RZ_SCALAR_UNIFORM
             const DevPair* upp = reinterpret_cast<const DevPair*>(
-                ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)pp >> 32)) << 32) |
-                (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)pp));
+                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)pp >> 32)) << 32) |
+                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)pp));
+            // (the builtin returns a signed int: without the (unsigned) a low half with bit 31 set sign-extended over
+            //  the high half, the comparison below then failed for every lane and the scalar path was never taken --
+            //  half of all buffer placements ran 5.7 % slower, found from a 2x TCP access count in the slow runs)
             if (__ballot(pp != upp) == 0ull) {       // every active lane wants the same pair: one scalar fetch,
                 RZ_SITE(c, 7);                        // box values consumed straight from SGPRs
                 const f32x16 q = sload16(upp);
