@@ -32,7 +32,7 @@
 namespace rz {
 
 #ifndef RZ_DESCEND_MIN_LANES
-#define RZ_DESCEND_MIN_LANES 8   // leave the descend loop when fewer lanes than this still have an internal node (measured: 1 -> 125 ms, 8 -> 99 ms, 16 -> 105 ms on C2)
+#define RZ_DESCEND_MIN_LANES 4   // leave the descend loop when fewer lanes than this still have an internal node (lane=sample kernel on C2: 1 -> 17.6 ms, 2 -> 17.4, 3..6 -> 17.15-17.2, 8 -> 17.3, 12 -> 17.4)
 #endif
 
 struct Tally {          // per-thread counts of the REFERENCE algorithm's memory touches
@@ -224,7 +224,9 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
             {
                 const float4* __restrict__ p4 = reinterpret_cast<const float4*>(pp);
                 float4 p0 = p4[0], p1 = p4[1], p2 = p4[2], p3 = p4[3];
+#ifndef RZ_EXP_NOKEEP
                 RZ_KEEP4(p0); RZ_KEEP4(p3);
+#endif
                 const f32x2 lx = {p0.x, p0.y}, ly = {p0.z, p0.w}, lz = {p1.x, p1.y};
                 const f32x2 rx = {p1.z, p1.w}, ry = {p2.x, p2.y}, rz = {p2.z, p2.w};
                 RZ_SLAB_PAIR("v", RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
