@@ -112,7 +112,7 @@ struct rz_ctx {
     bool geomDirty = true, instDirty = true, tlasDirty = true, matDirty = true, lightDirty = true;
 
     // device scene
-    DevBuf dPairs, dTris, dInst, dTlasNodes, dTlasIdx, dMat, dLight, dCounters, dResolve;
+    DevBuf dPairs, dTris, dInst, dTlasNodes, dTlasIdx, dMat, dLight, dCounters, dResolve, dGroupCtr;
     std::map<std::tuple<int, int, int>, BlasView> views;
     std::vector<DevPair> hPairs;
     std::vector<DevTri> hTris;
@@ -477,6 +477,9 @@ bool use_samples(const rz_ctx* c) { return (c->flags & RZ_FLAG_MEGAKERNEL) == 0;
 
 int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     K.nSlots = K.nLocalTiles * 64;
+    int rc = ensure(c, c->dGroupCtr, 256);
+    if (rc != RZ_OK) return rc;
+    K.groupCounter = static_cast<unsigned*>(c->dGroupCtr.p);
     RZ_HIP(c, hipEventRecord(c->evStart[evSlot], c->stream));
     if (K.nSlots > 0) launch_render_samples(K, counted, c->sceneHasTransparency, c->stream);
     RZ_HIP(c, hipEventRecord(c->evStop[evSlot], c->stream));
@@ -635,7 +638,7 @@ void rz_destroy(rz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
-                      &c->dCounters, &c->dResolve, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs})
+                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs})
         b->release();
     if (c->wfHostCount) (void)hipHostFree(c->wfHostCount);
     if (c->tlasHostCounts) (void)hipHostFree(c->tlasHostCounts);

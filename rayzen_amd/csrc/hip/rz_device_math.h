@@ -115,6 +115,18 @@ __device__ __forceinline__ float cos_(float x) {
     if ((t.q + 1) & 2) v = -v;
     return (float)v;
 }
+// sin and cos of the same angle from ONE argument reduction and ONE pair of polynomials: the values are those of
+// sin_(x) and cos_(x) bit for bit (same core, same selection).  Written out because KD() is volatile, which keeps
+// the compiler from merging the two cores by itself.
+__device__ __forceinline__ void sincos_(float x, float& s, float& c) {
+    SinCos t = sincos_core(x);
+    double vs = (t.q & 1) ? t.c : t.s;
+    if (t.q & 2) vs = -vs;
+    double vc = (t.q & 1) ? t.s : t.c;
+    if ((t.q + 1) & 2) vc = -vc;
+    s = (float)vs;
+    c = (float)vc;
+}
 __device__ __forceinline__ float acos_(float xf) {
     const double x = (double)xf;
     const double ax = __builtin_fabs(x);

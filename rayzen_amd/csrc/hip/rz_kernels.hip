@@ -166,9 +166,21 @@ __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
 #endif
 }
 
+// Persistent waves: the grid is RZ_PERSIST_WAVES_PER_CU waves per CU (>= what fits) and each wave claims
+// RZ_GROUPS_PER_CLAIM consecutive pixel groups at a time from a per-launch counter, instead of one workgroup per pixel:
+// at 1080p that was 2 M workgroup launches per frame, each paying dispatch, LDS allocation and kernarg loads for as
+// little as one sky lookup.  Measured on C2 (17.2 ms as one workgroup per pixel): static striding 26 / 21 / 18.8 ms
+// at 16 / 32 / 64 waves per CU (whole extra rounds: 15, not 16, waves are resident); claiming 2 / 4 / 6 / 8 / 12 /
+// 16 / 32 groups: 20.0 / 17.4 / 17.0 / 16.8 / 16.9 / 17.2 / 18.8 ms -- small claims run into the ~88 atomics/us a
+// single word sustains, large ones leave a tail.  8 groups = one row of an 8x8 tile.
+#ifndef RZ_PERSIST_WAVES_PER_CU
+#define RZ_PERSIST_WAVES_PER_CU 16
+#endif
+#ifndef RZ_GROUPS_PER_CLAIM
+#define RZ_GROUPS_PER_CLAIM 8
+#endif
 template <bool COUNT, bool GLASS>
-__global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES_MIN_WAVES) void rz_render_samples(const KParams K) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+__device__ __forceinline__ void render_samples_group(const KParams& K, const unsigned wblock, unsigned char* lds_raw) {
     const int lane = threadIdx.x & 63;
     uint2* bstk = reinterpret_cast<uint2*>(lds_raw) + lane;
     int* tstk = reinterpret_cast<int*>(lds_raw + (size_t)K.blasStackCap * 64 * sizeof(uint2)) + lane;
@@ -181,8 +193,8 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
     const int nBatches = spp >= 64 ? (spp + 63) / 64 : 1;
     // this lane's pixel (as a path-tracing lane) and this lane's pixel as a summing lane (lanes 0..pixPerWave-1)
     const int myPixInWave = spp >= 64 ? 0 : lane / spp;
-    const int slot = blockIdx.x * pixPerWave + myPixInWave;
-    const int sumSlot = blockIdx.x * pixPerWave + lane;
+    const int slot = (int)wblock * pixPerWave + myPixInWave;
+    const int sumSlot = (int)wblock * pixPerWave + lane;
     bool inside = false, sumInside = false;
     size_t sumPix = 0;
     Path P;
@@ -399,6 +411,20 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
     }
 }
 
+
+template <bool COUNT, bool GLASS>
+__global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES_MIN_WAVES) void rz_render_samples(const KParams K, const unsigned nGroups) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    for (;;) {
+        unsigned base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(K.groupCounter, (unsigned)RZ_GROUPS_PER_CLAIM);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= nGroups) break;             // every wave of the grid reaches this: the counter only grows
+        const unsigned end = base + RZ_GROUPS_PER_CLAIM < nGroups ? base + RZ_GROUPS_PER_CLAIM : nGroups;
+        for (unsigned wb = base; wb < end; ++wb) render_samples_group<COUNT, GLASS>(K, wb, lds_raw);
+    }
+}
+
 // FS:772-773 + 8-bit quantisation: rgba8 = round(clamp(sum / n, 0, 1) * 255), a = 255.
 __global__ void rz_resolve_kernel(const float4* __restrict__ accum, uchar4* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -456,13 +482,23 @@ void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream
     // after the stacks: 2 x 64 float4 of addends; the speculating variant keeps two versions + bookkeeping
     const size_t lds = (size_t)K.blasStackCap * 64 * sizeof(uint2) + (size_t)K.tlasStackCap * 64 * sizeof(int) +
                        (glass ? 4 * 64 * sizeof(float4) + 3 * 64 * sizeof(int) : 2 * 64 * sizeof(float4));
-    const dim3 g((unsigned)blocks), b(64);
+    static int nCU = 0;
+    if (nCU == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        nCU = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    const long long claims = (blocks + RZ_GROUPS_PER_CLAIM - 1) / RZ_GROUPS_PER_CLAIM;
+    const long long grid = std::min<long long>(claims, (long long)nCU * RZ_PERSIST_WAVES_PER_CU);
+    const dim3 g((unsigned)grid), b(64);
+    const unsigned nGroups = (unsigned)blocks;
+    if (hipMemsetAsync(K.groupCounter, 0, sizeof(unsigned), stream) != hipSuccess) return;
     if (glass) {
-        if (counted) hipLaunchKernelGGL((rz_render_samples<true, true>), g, b, lds, stream, K);
-        else hipLaunchKernelGGL((rz_render_samples<false, true>), g, b, lds, stream, K);
+        if (counted) hipLaunchKernelGGL((rz_render_samples<true, true>), g, b, lds, stream, K, nGroups);
+        else hipLaunchKernelGGL((rz_render_samples<false, true>), g, b, lds, stream, K, nGroups);
     } else {
-        if (counted) hipLaunchKernelGGL((rz_render_samples<true, false>), g, b, lds, stream, K);
-        else hipLaunchKernelGGL((rz_render_samples<false, false>), g, b, lds, stream, K);
+        if (counted) hipLaunchKernelGGL((rz_render_samples<true, false>), g, b, lds, stream, K, nGroups);
+        else hipLaunchKernelGGL((rz_render_samples<false, false>), g, b, lds, stream, K, nGroups);
     }
 }
 

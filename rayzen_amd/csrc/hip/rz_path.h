@@ -101,7 +101,9 @@ __device__ __forceinline__ v3 random_hemisphere_direction(v3 normal, v2 seed) {
     const float v = rand_(s1);
     const float theta = acos_(__builtin_sqrtf(1.0f - u));
     const float phi = (2.0f * 3.14159f) * v;
-    const float st = sin_(theta), ct = cos_(theta), sp = sin_(phi), cp = cos_(phi);
+    float st, ct, sp, cp;
+    sincos_(theta, st, ct);
+    sincos_(phi, sp, cp);
     const v3 dir = mk3(st * cp, st * sp, ct);
     const v3 up = (__builtin_fabsf(normal.y) < 0.99f) ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
     const v3 tangent = normalize(cross(up, normal));

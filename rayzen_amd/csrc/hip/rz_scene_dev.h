@@ -86,6 +86,7 @@ struct KParams {
     float4* accum;          // width*height RGBA32F, row 0 = bottom
     float* ior;             // width*height: FS:674's currentIor carried across rz_render calls
     DevCounters* counters;  // only for the counting build
+    unsigned* groupCounter; // next unclaimed pixel group of this launch (persistent waves, rz_kernels.hip); zeroed per launch
     int32_t nTlasNodes;
     int32_t nLights;        // min(numLights uniform, lights.length())  (FS:574-575)
     int32_t nMaterials;
