@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstdio>
 #include <vector>
 
@@ -413,14 +414,18 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
 
 
 template <bool COUNT, bool GLASS>
-__global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES_MIN_WAVES) void rz_render_samples(const KParams K, const unsigned nGroups) {
+__global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES_MIN_WAVES) void rz_render_samples(const KParams K, const unsigned nGroups, const unsigned perClaim) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (perClaim == 0) {                        // one workgroup per pixel group (small launches, spp < 64)
+        render_samples_group<COUNT, GLASS>(K, blockIdx.x, lds_raw);
+        return;
+    }
     for (;;) {
         unsigned base = 0;
-        if ((threadIdx.x & 63) == 0) base = atomicAdd(K.groupCounter, (unsigned)RZ_GROUPS_PER_CLAIM);
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(K.groupCounter, perClaim);
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= nGroups) break;             // every wave of the grid reaches this: the counter only grows
-        const unsigned end = base + RZ_GROUPS_PER_CLAIM < nGroups ? base + RZ_GROUPS_PER_CLAIM : nGroups;
+        const unsigned end = base + perClaim < nGroups ? base + perClaim : nGroups;
         for (unsigned wb = base; wb < end; ++wb) render_samples_group<COUNT, GLASS>(K, wb, lds_raw);
     }
 }
@@ -488,17 +493,22 @@ void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream
         nCU = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                   ? prop.multiProcessorCount : 256;
     }
-    const long long claims = (blocks + RZ_GROUPS_PER_CLAIM - 1) / RZ_GROUPS_PER_CLAIM;
-    const long long grid = std::min<long long>(claims, (long long)nCU * RZ_PERSIST_WAVES_PER_CU);
+    // Persistent waves pay off when a group is one pixel's 64-sample batches and there are many groups per resident
+    // wave (C2: 17.2 -> 16.8 ms, C5: 226 -> 203 ms).  With several pixels per wave (spp < 64) or a small frame the
+    // hardware dispatcher is the better scheduler (C4: 14.6 ms against 15.4-19.9 ms persistent; C1: 0.04 against 0.1-0.2).
+    long long perClaim = (K.spp >= 64 && blocks >= (long long)nCU * RZ_PERSIST_WAVES_PER_CU * 16) ? RZ_GROUPS_PER_CLAIM : 0;
+    if (const char* e = std::getenv("RZ_GROUPS_PER_CLAIM")) perClaim = std::max(0, std::atoi(e));      // tuning aid
+    const long long claims = perClaim ? (blocks + perClaim - 1) / perClaim : blocks;
+    const long long grid = perClaim ? std::min<long long>(claims, (long long)nCU * RZ_PERSIST_WAVES_PER_CU) : blocks;
     const dim3 g((unsigned)grid), b(64);
     const unsigned nGroups = (unsigned)blocks;
-    if (hipMemsetAsync(K.groupCounter, 0, sizeof(unsigned), stream) != hipSuccess) return;
+    if (perClaim && hipMemsetAsync(K.groupCounter, 0, sizeof(unsigned), stream) != hipSuccess) return;
     if (glass) {
-        if (counted) hipLaunchKernelGGL((rz_render_samples<true, true>), g, b, lds, stream, K, nGroups);
-        else hipLaunchKernelGGL((rz_render_samples<false, true>), g, b, lds, stream, K, nGroups);
+        if (counted) hipLaunchKernelGGL((rz_render_samples<true, true>), g, b, lds, stream, K, nGroups, (unsigned)perClaim);
+        else hipLaunchKernelGGL((rz_render_samples<false, true>), g, b, lds, stream, K, nGroups, (unsigned)perClaim);
     } else {
-        if (counted) hipLaunchKernelGGL((rz_render_samples<true, false>), g, b, lds, stream, K, nGroups);
-        else hipLaunchKernelGGL((rz_render_samples<false, false>), g, b, lds, stream, K, nGroups);
+        if (counted) hipLaunchKernelGGL((rz_render_samples<true, false>), g, b, lds, stream, K, nGroups, (unsigned)perClaim);
+        else hipLaunchKernelGGL((rz_render_samples<false, false>), g, b, lds, stream, K, nGroups, (unsigned)perClaim);
     }
 }
 
