@@ -322,6 +322,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
             const int nMine = spp >= 64 ? min(64, spp - b * 64) : spp;
             const int firstLane = spp >= 64 ? 0 : lane * spp;     // summing lanes: first lane of my pixel
             Tally tv[2] = {};
+            bool firstPass = true;
             __syncthreads();
             for (;;) {
                 const int cons = __shfl(consumed, pixLane);
@@ -354,6 +355,31 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
                     if (COUNT) tv[slot] = att;
                 }
                 __syncthreads();
+                if (firstPass && spp >= 64 && __ballot(mine && (infov[0] & 2)) == 0ull) {
+                    // Nobody in this batch read currentIor (the usual case: most pixels never meet glass): every
+                    // sample's only version is final, so add them as the opaque kernel does -- one colour channel per
+                    // lane, unrolled -- instead of one lane walking 64 keyed entries (that walk alone was a third of
+                    // the variant's instructions).  Same additions in the same order.
+                    const float ax = __shfl(acc.x, 0), ay = __shfl(acc.y, 0), az = __shfl(acc.z, 0);
+                    float ch = lane == 0 ? ax : (lane == 1 ? ay : az);
+                    if (lane < 3 && sumInside0) {
+                        const float* Lf = reinterpret_cast<const float*>(verL) + lane;
+                        const float* Sf = reinterpret_cast<const float*>(verS) + lane;
+                        int k = 0;
+                        for (; k + 8 <= nMine; k += 8) {
+                            float l[8], q[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { l[u] = Lf[4 * (k + u)]; q[u] = Sf[4 * (k + u)]; }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { ch = ch + l[u]; ch = ch + q[u]; }   // FS:717, FS:709
+                        }
+                        for (; k < nMine; ++k) { ch = ch + Lf[4 * k]; ch = ch + Sf[4 * k]; }
+                    }
+                    const float cx = __shfl(ch, 0), cy = __shfl(ch, 1), cz = __shfl(ch, 2);
+                    if (sumInside) { acc.x = cx; acc.y = cy; acc.z = cz; consumed = nMine; }
+                    chosen[lane] = 0;
+                }
+                firstPass = false;
                 if (sumInside) {
                     while (consumed < nMine) {
                         const int k = firstLane + consumed;
