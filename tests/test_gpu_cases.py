@@ -183,6 +183,18 @@ def test_full_size_c2_sampled_bands_and_properties():
     assert ((halves[0] + halves[1]).view(np.uint32) == gpu.view(np.uint32)).all()
 
 
+def test_full_frame_every_pixel_c2_and_a_glass_scene():
+    """Every one of the 2 073 600 pixels, not a sample of bands: C2 itself (opaque kernel, 132.7 M paths, about 12 s of
+    oracle time on 16 threads) and the glass + mirror variant of the scene at 16 spp / 5 bounces (speculating kernel)."""
+    from oracle import rzo
+    from helpers import oracle_frame, oracle_scene
+    W, H = 1920, 1080
+    for sc, spp, b in ((S.bunny_scene(n=76, aspect=W / H), 64, 4), (S.bunny_scene(n=76, aspect=W / H, extras=True), 16, 5)):
+        gpu = hip_render(sc, W, H, spp, b)
+        ref = rzo.render(oracle_scene(sc), oracle_frame(sc, W, H, spp, b), nthreads=16)
+        assert (gpu.view(np.uint32) == ref.view(np.uint32)).all(), mismatch_report(gpu, ref)
+
+
 def test_cpp_frontend_example_builds_and_renders(tmp_path):
     """examples/render_scene.cpp: RayZen-style C++ frontend -> Renderer.h -> C-ABI -> GPU."""
     import os
