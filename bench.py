@@ -179,6 +179,19 @@ def main():
                            "algorithmic_bytes_per_launch": int(alg_bytes),
                            "algorithmic_bytes_per_sample": round(alg_bytes / max(counters["samples"], 1), 1),
                            "kernel_msamples_per_s": round(counters["samples"] / (kms * 1e-3) / 1e6, 2)}
+        # what does bound it: the issue-side counters of the committed PMC passes (same workload), not re-measured here
+        ppath = os.path.join(ROOT, "profiles", "r01_sample_kernel_v2", "pmc_rz_render_samples.json")
+        if traffic is not None and os.path.exists(ppath):
+            try:
+                pj = json.load(open(ppath))
+                simd_cycles = pj["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+                out["roofline"]["issue"] = {
+                    "valu_busy_frac": round(4.0 * pj["SQ_ACTIVE_INST_VALU"] / simd_cycles, 3),
+                    "valu_lane_utilisation": round(pj["SQ_THREAD_CYCLES_VALU"] / (64.0 * pj["SQ_ACTIVE_INST_VALU"]), 3),
+                    "valu_wave_instructions_per_launch": int(pj["SQ_INSTS_VALU"]),
+                    "source": "profiles/r01_sample_kernel_v2/pmc_rz_render_samples.json (rocprofv3 --pmc, separate passes)"}
+            except Exception:
+                pass
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import rzo
         from helpers import oracle_frame, oracle_scene
