@@ -109,3 +109,20 @@ def test_scene_build_with_the_device_builder_gives_the_same_buffers(r):
     dev.build()
     for b in S.GEOMETRY_BINDINGS:
         assert dev.arrays[b].tobytes() == host.arrays[b].tobytes(), b
+
+
+def test_rz_build_blas_argument_errors(r):
+    import ctypes as C
+    from rayzen_amd.renderer import RayZenError
+    L, c = r._L, r._c
+    t = soup(100, 1)
+    nodes = np.zeros(199, S.BVH_NODE)
+    idx = np.zeros(100, np.int32)
+    nn = C.c_size_t(0)
+    assert L.rz_build_blas(c, t.ctypes.data, 100, nodes.ctypes.data, 50, idx.ctypes.data, C.byref(nn), None, None) == -7   # RZ_ERR_BUFFER_SIZE
+    assert L.rz_build_blas(c, None, 100, nodes.ctypes.data, 199, idx.ctypes.data, C.byref(nn), None, None) == -1
+    assert L.rz_build_blas(c, t.ctypes.data, 100, None, 199, idx.ctypes.data, C.byref(nn), None, None) == -1
+    assert L.rz_build_blas(None, t.ctypes.data, 100, nodes.ctypes.data, 199, idx.ctypes.data, C.byref(nn), None, None) == -1
+    assert L.rz_build_blas(c, t.ctypes.data, 100, nodes.ctypes.data, 199, idx.ctypes.data, C.byref(nn), None, None) == 0
+    hn, hi, _ = S.build_blas(t)
+    assert nodes[:nn.value].tobytes() == hn.tobytes() and idx.tobytes() == hi.tobytes()

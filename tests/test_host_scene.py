@@ -3,6 +3,7 @@ OBJ reader (Mesh.cpp:6-50), against the oracle's literal restatements."""
 import os
 
 import numpy as np
+import pytest
 
 from oracle import rzo
 from rayzen_amd import scene as S
@@ -143,3 +144,41 @@ def test_scene_cache_round_trip_in_rayzen_format(tmp_path):
     import pytest
     with pytest.raises(OSError):
         S.Scene().load_cache(d)
+
+
+def test_blas_builder_hook_is_used_and_its_failure_is_reported():
+    """rzh_scene_set_blas_builder: scene assembly calls a function with rz_build_blas's signature for every distinct
+    mesh (here the host builder wrapped as a callback, so no GPU is needed) and reports its failure instead of
+    silently building on the host."""
+    import ctypes as C
+    from rayzen_amd import _lib
+    proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                        C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_float))
+    calls = []
+
+    def builder(ctx, tris, n, nodes_out, cap, idx_out, n_nodes, depth, ms):
+        calls.append(int(n))
+        if fail[0]:
+            return -3
+        d = C.c_int(0)
+        nn = _lib.host().rzh_build_blas(tris, n, nodes_out, idx_out, C.byref(d))
+        assert 0 < nn <= cap
+        n_nodes[0] = nn
+        return 0
+
+    fail = [False]
+    cb = proto(builder)
+    ref = S.bunny_scene(n=6, extras=True)
+    s = S.bunny_scene(n=6, extras=True)
+    assert _lib.host().rzh_scene_set_blas_builder(s._h, C.cast(cb, C.c_void_p), None) == 0
+    s.build()
+    assert sorted(calls) == sorted(int(m) for m in (12, 12 * 36, 12 * 16, 12))     # floor, bunny, glass blob, mirror cube
+    for b in S.GEOMETRY_BINDINGS:
+        assert s.arrays[b].tobytes() == ref.arrays[b].tobytes()
+    fail[0] = True
+    with pytest.raises(RuntimeError, match="device BLAS builder failed"):
+        s.build()
+    s.set_blas_builder(None)
+    s.build()
+    for b in S.GEOMETRY_BINDINGS:
+        assert s.arrays[b].tobytes() == ref.arrays[b].tobytes()
