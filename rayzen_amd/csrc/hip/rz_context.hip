@@ -511,10 +511,6 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     K.materials = static_cast<const DevMaterial*>(c->dMat.p);
     K.lights = static_cast<const DevLight*>(c->dLight.p);
     K.accum = accum;
-    if (std::getenv("RZ_DEBUG_PTRS")) {
-        static int once = 0;
-        if (once++ < 64) std::fprintf(stderr, "rz ptrs: pairs %p tris %p inst %p tlasN %p tlasI %p mat %p light %p accum %p\n", (void*)K.pairs, (void*)K.tris, (void*)K.instances, (void*)K.tlasNodes, (void*)K.tlasIndices, (void*)K.materials, (void*)K.lights, (void*)K.accum);
-    }
     K.ior = static_cast<float*>(c->dIor.p);
     K.nTlasNodes = c->deviceOwnsTlas ? c->devTlasNodes : (int)hostCount<rz_bvh_node>(c, RZ_BIND_TLAS_NODES);
     K.nLights = std::max(0, std::min<int>(f.num_lights, (int)hostCount<rz_light>(c, RZ_BIND_LIGHTS)));
@@ -528,7 +524,8 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     K.maxBounces = f.bounce_budget > 0 ? f.bounce_budget : 5;      // FS:673
     K.spp = f.spp; K.sampleBase = f.sample_base;
     K.blasStackCap = std::max(1, c->maxBlasDepth - 1);
-    K.tlasStackCap = std::min(64, std::max(2, c->tlasDepth + 1));  // FS:460: stack[64]
+    // a pop followed by two pushes never holds more entries than the tree has levels (FS:460: stack[64])
+    K.tlasStackCap = std::min(64, std::max(2, c->tlasDepth));
     std::memcpy(K.invView, f.inv_view, 64);
     std::memcpy(K.invProj, f.inv_proj, 64);
     std::memcpy(K.camPos, f.cam_pos, 12);

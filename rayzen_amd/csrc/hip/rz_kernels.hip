@@ -187,7 +187,6 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
     int* tstk = reinterpret_cast<int*>(lds_raw + (size_t)K.blasStackCap * 64 * sizeof(uint2)) + lane;
     float4* addL = reinterpret_cast<float4*>(lds_raw + (size_t)K.blasStackCap * 64 * sizeof(uint2) +
                                              (size_t)K.tlasStackCap * 64 * sizeof(int));
-    float4* addS = addL + 64;
 
     const int spp = K.spp;
     const int pixPerWave = spp >= 64 ? 1 : 64 / spp;
@@ -227,8 +226,6 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
     // currentIor entering this pixel's next sample, held by the pixel's summing lane and fetched by its path lanes
     float iorPix = (GLASS && sumInside && K.sampleBase != 0) ? K.ior[sumPix] : 1.0f;
     const int pixLane = spp >= 64 ? 0 : myPixInWave;         // the summing lane of this path lane's pixel
-    const unsigned long long segMask =                       // the lanes holding samples of this lane's pixel
-        spp >= 64 ? ~0ull : (((1ull << spp) - 1ull) << (myPixInWave * spp));
     // spp >= 64: the wave's single pixel, summed per channel by lanes 0..2 (lane 3 keeps the sample count)
     const bool sumInside0 = __shfl((int)sumInside, 0) != 0;
     const size_t sumPix0 = ((size_t)(unsigned)__shfl((int)(sumPix >> 32), 0) << 32) | (unsigned)__shfl((int)(unsigned)sumPix, 0);
@@ -272,32 +269,35 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
 #endif
             }
             // park the addends (zeros for idle lanes: adding +0 is exact), then replay the adds in sample order
-            addL[lane] = make_float4(P.addLight.x, P.addLight.y, P.addLight.z, 0.0f);
-            addS[lane] = make_float4(P.addSky.x, P.addSky.y, P.addSky.z, 0.0f);
+            // (channel-major [3][64] + [3][64] floats: 1.5 KB, and the channel lanes below read consecutive words)
+            float* const aL = reinterpret_cast<float*>(addL);
+            float* const aS = aL + 3 * 64;
+            aL[lane] = P.addLight.x; aL[64 + lane] = P.addLight.y; aL[128 + lane] = P.addLight.z;
+            aS[lane] = P.addSky.x; aS[64 + lane] = P.addSky.y; aS[128 + lane] = P.addSky.z;
             __syncthreads();
             if (spp >= 64) {
                 // one pixel per wave: the three colour channels are independent chains -> lanes 0,1,2 take one each
                 // (a 128-add dependent chain per batch instead of 384 on one lane)
                 if (lane < 3 && sumInside0) {
-                    const float* Lf = reinterpret_cast<const float*>(addL) + lane;
-                    const float* Sf = reinterpret_cast<const float*>(addS) + lane;
+                    const float* Lf = aL + 64 * lane;
+                    const float* Sf = aS + 64 * lane;
                     const int n = min(64, spp - b * 64);
                     int k = 0;
                     for (; k + 8 <= n; k += 8) {
                         float l[8], q[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) { l[u] = Lf[4 * (k + u)]; q[u] = Sf[4 * (k + u)]; }
+                        for (int u = 0; u < 8; ++u) { l[u] = Lf[k + u]; q[u] = Sf[k + u]; }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) { chan = chan + l[u]; chan = chan + q[u]; }   // FS:717, FS:709
                     }
-                    for (; k < n; ++k) { chan = chan + Lf[4 * k]; chan = chan + Sf[4 * k]; }
+                    for (; k < n; ++k) { chan = chan + Lf[k]; chan = chan + Sf[k]; }
                 }
             } else if (sumInside) {
                 const int first = lane * spp;
                 for (int k = 0; k < spp; ++k) {
-                    const float4 L = addL[first + k], S = addS[first + k];
-                    acc.x = acc.x + L.x; acc.y = acc.y + L.y; acc.z = acc.z + L.z;     // FS:717
-                    acc.x = acc.x + S.x; acc.y = acc.y + S.y; acc.z = acc.z + S.z;     // FS:709
+                    const int e = first + k;
+                    acc.x = acc.x + aL[e]; acc.y = acc.y + aL[64 + e]; acc.z = acc.z + aL[128 + e];     // FS:717
+                    acc.x = acc.x + aS[e]; acc.y = acc.y + aS[64 + e]; acc.z = acc.z + aS[128 + e];     // FS:709
                 }
             }
             __syncthreads();
@@ -512,7 +512,7 @@ void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream
     if (blocks <= 0) return;
     // after the stacks: 2 x 64 float4 of addends; the speculating variant keeps two versions + bookkeeping
     const size_t lds = (size_t)K.blasStackCap * 64 * sizeof(uint2) + (size_t)K.tlasStackCap * 64 * sizeof(int) +
-                       (glass ? 4 * 64 * sizeof(float4) + 3 * 64 * sizeof(int) : 2 * 64 * sizeof(float4));
+                       (glass ? 4 * 64 * sizeof(float4) + 3 * 64 * sizeof(int) : 6 * 64 * sizeof(float));
     static int nCU = 0;
     if (nCU == 0) {
         int dev = 0; hipDeviceProp_t prop;
