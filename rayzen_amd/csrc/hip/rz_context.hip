@@ -40,6 +40,8 @@ int blas_build_device(const rz_triangle* hostTris, size_t n, void* workspace, si
 void dump_wave_log(int nWaves);
 #endif
 void launch_render_pixels(const KParams& K, bool counted, hipStream_t stream);
+SamplesPlan plan_render_samples(int spp, int nSlots);
+size_t samples_lds_extra(bool glass);
 void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream_t stream);
 void launch_resolve(const float4* accum, uchar4* out, int n, hipStream_t stream);
 struct PresentParams {      // rz_present.hip
@@ -112,7 +114,7 @@ struct rz_ctx {
     bool geomDirty = true, instDirty = true, tlasDirty = true, matDirty = true, lightDirty = true;
 
     // device scene
-    DevBuf dPairs, dTris, dInst, dTlasNodes, dTlasIdx, dMat, dLight, dCounters, dResolve, dGroupCtr;
+    DevBuf dPairs, dTris, dInst, dTlasNodes, dTlasIdx, dMat, dLight, dCounters, dResolve, dGroupCtr, dBlasOvf;
     std::map<std::tuple<int, int, int>, BlasView> views;
     std::vector<DevPair> hPairs;
     std::vector<DevTri> hTris;
@@ -480,6 +482,24 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     int rc = ensure(c, c->dGroupCtr, 256);
     if (rc != RZ_OK) return rc;
     K.groupCounter = static_cast<unsigned*>(c->dGroupCtr.p);
+    // LDS budget: the BLAS stack's LDS window is cut to what keeps the target number of waves on a CU (16 for the
+    // opaque variant = its VGPR limit, 12 for the transparent one); deeper entries go to global overflow columns,
+    // which are indexed by resident workgroup and therefore only exist for persistent launches.
+    const SamplesPlan plan = plan_render_samples(K.spp, K.nSlots);
+    const int need = K.blasStackCap;
+    const size_t budget = (size_t)160 * 1024 / (c->sceneHasTransparency ? 12 : 16);
+    const size_t fixed = samples_lds_extra(c->sceneHasTransparency) + (size_t)K.tlasStackCap * 256;
+    int window = budget > fixed ? (int)((budget - fixed) / 512) : 0;
+    if (const char* e = std::getenv("RZ_BLAS_STACK_WINDOW")) window = std::atoi(e);        // test aid: force a small window
+    window = std::max(window, 2);
+    K.blasOvfCap = 0; K.blasOvf = nullptr;
+    if (plan.perClaim > 0 && need > window) {
+        K.blasStackCap = window;
+        K.blasOvfCap = need - window;
+        rc = ensure(c, c->dBlasOvf, (size_t)plan.grid * K.blasOvfCap * 64 * sizeof(uint2));
+        if (rc != RZ_OK) return rc;
+        K.blasOvf = static_cast<uint2*>(c->dBlasOvf.p);
+    }
     RZ_HIP(c, hipEventRecord(c->evStart[evSlot], c->stream));
     if (K.nSlots > 0) launch_render_samples(K, counted, c->sceneHasTransparency, c->stream);
     RZ_HIP(c, hipEventRecord(c->evStop[evSlot], c->stream));
@@ -635,7 +655,7 @@ void rz_destroy(rz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
-                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs})
+                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs})
         b->release();
     if (c->wfHostCount) (void)hipHostFree(c->wfHostCount);
     if (c->tlasHostCounts) (void)hipHostFree(c->tlasHostCounts);

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
     // LDS: per wave, [blasStackCap][64] uint2 then [tlasStackCap][64] int
     const size_t perWave = (size_t)K.blasStackCap * 64 * sizeof(uint2) + (size_t)K.tlasStackCap * 64 * sizeof(int);
     unsigned char* base = lds_raw + perWave * wave;
-    uint2* bstk = reinterpret_cast<uint2*>(base) + lane;
+    const BlasStackT<false> bstk{reinterpret_cast<uint2*>(base) + lane, nullptr, K.blasStackCap};
     int* tstk = reinterpret_cast<int*>(base + (size_t)K.blasStackCap * 64 * sizeof(uint2)) + lane;
 
     const int localTile = blockIdx.x * WAVES_PER_BLOCK + wave;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
         if (P.mode == MODE_DONE) { RZ_SITE(c, 7); begin_sample<COUNT>(K, P, c); }
         unsigned long long t1 = __builtin_amdgcn_s_memtime();
         HitRec h;
-        const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, c);
+        const bool found = trace_closest<COUNT, false>(K, P.o, P.d, h, bstk, tstk, c);
         unsigned long long t2 = __builtin_amdgcn_s_memtime();
         advance<COUNT>(K, P, found, h, c);
         unsigned long long t3 = __builtin_amdgcn_s_memtime();
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
 #else
         if (P.mode == MODE_DONE) begin_sample<COUNT>(K, P, c);
         HitRec h;
-        const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, c);
+        const bool found = trace_closest<COUNT, false>(K, P.o, P.d, h, bstk, tstk, c);
         advance<COUNT>(K, P, found, h, c);
 #endif
     }
@@ -180,10 +180,12 @@ __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
 #ifndef RZ_GROUPS_PER_CLAIM
 #define RZ_GROUPS_PER_CLAIM 8
 #endif
-template <bool COUNT, bool GLASS>
+template <bool COUNT, bool GLASS, bool OVF>
 __device__ __forceinline__ void render_samples_group(const KParams& K, const unsigned wblock, unsigned char* lds_raw) {
     const int lane = threadIdx.x & 63;
-    uint2* bstk = reinterpret_cast<uint2*>(lds_raw) + lane;
+    // (the overflow columns are indexed by the RESIDENT workgroup: blasOvfCap > 0 only in persistent launches)
+    const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + lane,
+                               OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + lane : nullptr, K.blasStackCap};
     int* tstk = reinterpret_cast<int*>(lds_raw + (size_t)K.blasStackCap * 64 * sizeof(uint2)) + lane;
     float4* addL = reinterpret_cast<float4*>(lds_raw + (size_t)K.blasStackCap * 64 * sizeof(uint2) +
                                              (size_t)K.tlasStackCap * 64 * sizeof(int));
@@ -259,7 +261,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
                 HitRec h;
-                const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, c);
+                const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, tstk, c);
 #ifdef RZ_PROF
                 const unsigned long long t2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -341,7 +343,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
                 }
                 while (P.mode != MODE_DONE) {
                     HitRec h;
-                    const bool found = trace_closest<COUNT>(K, P.o, P.d, h, bstk, tstk, COUNT ? att : c);
+                    const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, tstk, COUNT ? att : c);
                     advance<COUNT, true>(K, P, found, h, COUNT ? att : c);
                 }
                 if (run) {
@@ -439,11 +441,11 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
 }
 
 
-template <bool COUNT, bool GLASS>
+template <bool COUNT, bool GLASS, bool OVF>
 __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES_MIN_WAVES) void rz_render_samples(const KParams K, const unsigned nGroups, const unsigned perClaim) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (perClaim == 0) {                        // one workgroup per pixel group (small launches, spp < 64)
-        render_samples_group<COUNT, GLASS>(K, blockIdx.x, lds_raw);
+        render_samples_group<COUNT, GLASS, OVF>(K, blockIdx.x, lds_raw);
         return;
     }
     for (;;) {
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= nGroups) break;             // every wave of the grid reaches this: the counter only grows
         const unsigned end = base + perClaim < nGroups ? base + perClaim : nGroups;
-        for (unsigned wb = base; wb < end; ++wb) render_samples_group<COUNT, GLASS>(K, wb, lds_raw);
+        for (unsigned wb = base; wb < end; ++wb) render_samples_group<COUNT, GLASS, OVF>(K, wb, lds_raw);
     }
 }
 
@@ -506,36 +508,48 @@ void dump_wave_log(int nWaves) {
 }
 #endif
 
-void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream_t stream) {
-    const int pixPerWave = K.spp >= 64 ? 1 : 64 / K.spp;
-    const long long blocks = ((long long)K.nSlots + pixPerWave - 1) / pixPerWave;
-    if (blocks <= 0) return;
-    // after the stacks: 2 x 64 float4 of addends; the speculating variant keeps two versions + bookkeeping
-    const size_t lds = (size_t)K.blasStackCap * 64 * sizeof(uint2) + (size_t)K.tlasStackCap * 64 * sizeof(int) +
-                       (glass ? 4 * 64 * sizeof(float4) + 3 * 64 * sizeof(int) : 6 * 64 * sizeof(float));
+// How a frame is launched: one workgroup per pixel group, or a persistent grid claiming `perClaim` groups per atomic.
+// Persistent waves pay off when a group is one pixel's 64-sample batches and there are many groups per resident wave
+// (C2: 17.2 -> 16.8 ms, C5: 226 -> 203 ms).  With several pixels per wave (spp < 64) or a small frame the hardware
+// dispatcher is the better scheduler (C4: 14.6 ms against 15.4-19.9 ms persistent; C1: 0.04 against 0.1-0.2).
+SamplesPlan plan_render_samples(int spp, int nSlots) {
+    SamplesPlan p{};
+    const int pixPerWave = spp >= 64 ? 1 : 64 / spp;
+    p.groups = ((long long)nSlots + pixPerWave - 1) / pixPerWave;
     static int nCU = 0;
     if (nCU == 0) {
         int dev = 0; hipDeviceProp_t prop;
         nCU = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                   ? prop.multiProcessorCount : 256;
     }
-    // Persistent waves pay off when a group is one pixel's 64-sample batches and there are many groups per resident
-    // wave (C2: 17.2 -> 16.8 ms, C5: 226 -> 203 ms).  With several pixels per wave (spp < 64) or a small frame the
-    // hardware dispatcher is the better scheduler (C4: 14.6 ms against 15.4-19.9 ms persistent; C1: 0.04 against 0.1-0.2).
-    long long perClaim = (K.spp >= 64 && blocks >= (long long)nCU * RZ_PERSIST_WAVES_PER_CU * 16) ? RZ_GROUPS_PER_CLAIM : 0;
-    if (const char* e = std::getenv("RZ_GROUPS_PER_CLAIM")) perClaim = std::max(0, std::atoi(e));      // tuning aid
-    const long long claims = perClaim ? (blocks + perClaim - 1) / perClaim : blocks;
-    const long long grid = perClaim ? std::min<long long>(claims, (long long)nCU * RZ_PERSIST_WAVES_PER_CU) : blocks;
+    p.perClaim = (spp >= 64 && p.groups >= (long long)nCU * RZ_PERSIST_WAVES_PER_CU * 16) ? RZ_GROUPS_PER_CLAIM : 0;
+    if (const char* e = std::getenv("RZ_GROUPS_PER_CLAIM")) p.perClaim = std::max(0, std::atoi(e));      // tuning aid
+    const long long claims = p.perClaim ? (p.groups + p.perClaim - 1) / p.perClaim : p.groups;
+    p.grid = p.perClaim ? std::min<long long>(claims, (long long)nCU * RZ_PERSIST_WAVES_PER_CU) : p.groups;
+    return p;
+}
+size_t samples_lds_extra(bool glass) {      // LDS per wave besides the two stacks
+    return glass ? 4 * 64 * sizeof(float4) + 3 * 64 * sizeof(int) : 6 * 64 * sizeof(float);
+}
+
+void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream_t stream) {
+    const SamplesPlan plan = plan_render_samples(K.spp, K.nSlots);
+    const long long blocks = plan.groups, grid = plan.grid, perClaim = plan.perClaim;
+    if (blocks <= 0) return;
+    const size_t lds = (size_t)K.blasStackCap * 64 * sizeof(uint2) + (size_t)K.tlasStackCap * 64 * sizeof(int) + samples_lds_extra(glass);
     const dim3 g((unsigned)grid), b(64);
     const unsigned nGroups = (unsigned)blocks;
     if (perClaim && hipMemsetAsync(K.groupCounter, 0, sizeof(unsigned), stream) != hipSuccess) return;
+    const bool ovf = K.blasOvfCap > 0;           // only set for persistent launches (rz_context.hip: render_samples)
+#define RZ_LAUNCH_SAMPLES(C, G, O) hipLaunchKernelGGL((rz_render_samples<C, G, O>), g, b, lds, stream, K, nGroups, (unsigned)perClaim)
     if (glass) {
-        if (counted) hipLaunchKernelGGL((rz_render_samples<true, true>), g, b, lds, stream, K, nGroups, (unsigned)perClaim);
-        else hipLaunchKernelGGL((rz_render_samples<false, true>), g, b, lds, stream, K, nGroups, (unsigned)perClaim);
+        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, true, true); else RZ_LAUNCH_SAMPLES(true, true, false); }
+        else { if (ovf) RZ_LAUNCH_SAMPLES(false, true, true); else RZ_LAUNCH_SAMPLES(false, true, false); }
     } else {
-        if (counted) hipLaunchKernelGGL((rz_render_samples<true, false>), g, b, lds, stream, K, nGroups, (unsigned)perClaim);
-        else hipLaunchKernelGGL((rz_render_samples<false, false>), g, b, lds, stream, K, nGroups, (unsigned)perClaim);
+        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, false, true); else RZ_LAUNCH_SAMPLES(true, false, false); }
+        else { if (ovf) RZ_LAUNCH_SAMPLES(false, false, true); else RZ_LAUNCH_SAMPLES(false, false, false); }
     }
+#undef RZ_LAUNCH_SAMPLES
 }
 
 void launch_resolve(const float4* accum, uchar4* out, int n, hipStream_t stream) {

@@ -97,11 +97,17 @@ struct KParams {
     int32_t maxBounces;
     int32_t spp, sampleBase;
     int32_t nSlots;         // nLocalTiles * 64
-    int32_t blasStackCap;   // LDS entries per lane for the BLAS stack (>= max BLAS depth)
+    int32_t blasStackCap;   // LDS entries per lane for the BLAS stack: the whole stack (max BLAS depth - 1), or a window of it
     int32_t tlasStackCap;
     float invView[16];
     float invProj[16];
     float camPos[3];
+    int32_t blasOvfCap;     // entries per lane beyond the LDS window, kept in global memory (persistent launches only; else 0)
+    uint2* blasOvf;         // [resident wave][blasOvfCap][64 lanes]
 };
+
+// How rz_render_samples is launched (rz_kernels.hip: plan_render_samples): groups of pixels, the grid, and the number
+// of groups a persistent wave claims per atomic (0: one workgroup per group).
+struct SamplesPlan { long long groups, grid; int perClaim; };
 
 }  // namespace rz

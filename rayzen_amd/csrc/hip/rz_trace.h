@@ -164,21 +164,47 @@ __device__ __forceinline__ v3 x34_normal(const float* m, v3 v) {   // mat3(trans
 // Pop one stack entry.  The shader's cull `tmin > tHit` (FS:430) is evaluated here, against the CURRENT tLoc; a
 // culled entry becomes an empty leaf (enc -1 = ~((0 << 4) | 0)): the next leaf phase tests none of its zero
 // triangles and pops again.  Same visits in the same order, without an inner pop-until-unculled loop.
-__device__ __forceinline__ bool pop_entry(uint2* bstk, int& sp, float tLoc, int& cur) {
+// The stack: entries [0, W) live in LDS (this lane's column, 64 apart), deeper ones -- when the scene's deepest BLAS
+// does not fit the LDS budget that keeps 16 waves on a CU -- in a global-memory column of the same shape.  A ray's
+// stack holds one entry per level at which BOTH children were hit, typically well under half the tree depth, so the
+// overflow is touched by few lanes; W == capacity and ovf == nullptr when everything fits.
+// OVF is a compile-time property of the launch: the window test costs the common case (everything in LDS) 6 % if left in.
+template <bool OVF>
+struct BlasStackT { uint2* lds; uint2* ovf; int W; };
+template <bool OVF>
+__device__ __forceinline__ void push_entry(const BlasStackT<OVF>& S, int& sp, uint2 e) {
+    if (!OVF || sp < S.W) {
+        S.lds[sp * 64] = e;
+    } else {
+        uint2* q = S.ovf + (sp - S.W) * 64;
+        asm volatile("" : "+v"(q));      // opaque to the optimiser (hipcc crashed merging this store with the LDS one)
+        *q = e;
+    }
+    ++sp;
+}
+template <bool OVF>
+__device__ __forceinline__ bool pop_entry(const BlasStackT<OVF>& S, int& sp, float tLoc, int& cur) {
     if (sp <= 0) return false;
     --sp;
-    uint2 e = bstk[sp * 64];
+    uint2 e;
+    if (!OVF || sp < S.W) {
+        e = S.lds[sp * 64];
+    } else {
+        const uint2* q = S.ovf + (sp - S.W) * 64;
+        asm volatile("" : "+v"(q));
+        e = *q;
+    }
     asm volatile("" : "+v"(e.x), "+v"(e.y));     // one ds_read_b64
     cur = (__uint_as_float(e.y) > tLoc) ? -1 : (int)e.x;
     return true;
 }
 
 // One instance's BLAS (FS:419-454) in the instance's local space.
-// bstk: this lane's column of the LDS stack, entries 64 apart.
+// bstk: this lane's stack (LDS window + optional overflow).
 // Returns the winning triangle (absolute DevTri index) or -1; tLoc = its t.
-template <bool COUNT>
+template <bool COUNT, bool OVF>
 __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance* __restrict__ I, v3 lo, v3 ld,
-                                             float& tLocOut, uint2* bstk, Tally& c) {
+                                             float& tLocOut, const BlasStackT<OVF>& bstk, Tally& c) {
     float tLoc = 1e30f;
     int best = -1;
     const v3 inv = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
@@ -234,8 +260,7 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
                 renc = __float_as_int(p3.y);
             }
             if (hl) {
-                bstk[sp * 64] = make_uint2((unsigned)lenc, __float_as_uint(tl));
-                ++sp;
+                push_entry(bstk, sp, make_uint2((unsigned)lenc, __float_as_uint(tl)));
             }
             if (hr && !(tr > tLoc)) cur = renc;
             else go = pop_entry(bstk, sp, tLoc, cur);
@@ -266,8 +291,8 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
 }
 
 // FS:457-503.  tstk: this lane's column of the LDS TLAS stack (node ids).
-template <bool COUNT>
-__device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitRec& h, uint2* bstk, int* tstk,
+template <bool COUNT, bool OVF>
+__device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitRec& h, const BlasStackT<OVF>& bstk, int* tstk,
                                               Tally& c) {
     float tHit = 1e30f;
     int bestTri = -1, bestInst = -1;
@@ -295,7 +320,7 @@ __device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitR
                 const v3 lo = x34_point(I->inv, o);
                 const v3 ld = normalize(x34_dir(I->inv, d));
                 float tLoc;
-                const int tri = traverse_blas<COUNT>(K, I, lo, ld, tLoc, bstk, c);
+                const int tri = traverse_blas<COUNT, OVF>(K, I, lo, ld, tLoc, bstk, c);
                 if (tri >= 0) {
                     const v3 localHit = lo + ld * tLoc;              // FS:410
                     const v3 worldHit = x34_point(I->fwd, localHit); // FS:484

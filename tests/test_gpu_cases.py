@@ -352,3 +352,21 @@ def test_present_stage_matches_the_shader_tail(kw):
     assert (rgba8 == want_rgba8).all()
     if kw.get("show_fps", True):
         assert (rgba8[H - 24:H - 8, 8:100, :3] == 255).any()          # white digits in the top-left box
+
+
+@pytest.mark.parametrize("window", ["2", "5"])
+def test_blas_stack_overflow_columns_give_the_same_frame(window, monkeypatch):
+    """Deep trees keep only a window of the BLAS stack in LDS (so that 16 waves stay on a CU) and the rest in global
+    overflow columns.  Force a tiny window on a persistent-size frame: most pushes then go through the overflow."""
+    sc = S.bunny_scene(n=24, aspect=1280 / 1024, extras=False)
+    W, H, spp, b = 1280, 1024, 64, 3                 # 1.3 M pixel groups: the persistent launch is taken
+    ref = hip_render(sc, W, H, spp, b)
+    monkeypatch.setenv("RZ_BLAS_STACK_WINDOW", window)
+    got = hip_render(sc, W, H, spp, b)
+    assert (got.view(np.uint32) == ref.view(np.uint32)).all(), mismatch_report(got, ref)
+    y0 = 512
+    from helpers import oracle_frame, oracle_scene
+    from oracle import rzo
+    o = np.zeros_like(got)
+    rzo.render(oracle_scene(sc), oracle_frame(sc, W, H, spp, b), accum=o, crop=(0, y0, W, y0 + 8), nthreads=16)
+    assert (got[y0:y0 + 8].view(np.uint32) == o[y0:y0 + 8].view(np.uint32)).all()
