@@ -483,11 +483,15 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     if (rc != RZ_OK) return rc;
     K.groupCounter = static_cast<unsigned*>(c->dGroupCtr.p);
     // LDS budget: the BLAS stack's LDS window is cut to what keeps the target number of waves on a CU (16 for the
-    // opaque variant = its VGPR limit, 12 for the transparent one); deeper entries go to global overflow columns,
+    // opaque variant = its VGPR limit, and for the transparent one too: 5.4 KB of versions leave it a 9-entry window --
+    // measured 40.2 -> 34.3 ms on the glass+mirror scene against 12 waves with the whole stack in LDS); deeper entries go to global overflow columns,
     // which are indexed by resident workgroup and therefore only exist for persistent launches.
     const SamplesPlan plan = plan_render_samples(K.spp, K.nSlots);
     const int need = K.blasStackCap;
-    const size_t budget = (size_t)160 * 1024 / (c->sceneHasTransparency ? 12 : 16);
+#ifndef RZ_GLASS_WAVES_PER_CU
+#define RZ_GLASS_WAVES_PER_CU 16
+#endif
+    const size_t budget = (size_t)160 * 1024 / (c->sceneHasTransparency ? RZ_GLASS_WAVES_PER_CU : 16);
     const size_t fixed = samples_lds_extra(c->sceneHasTransparency) + (size_t)K.tlasStackCap * 256;
     int window = budget > fixed ? (int)((budget - fixed) / 512) : 0;
     if (const char* e = std::getenv("RZ_BLAS_STACK_WINDOW")) window = std::atoi(e);        // test aid: force a small window

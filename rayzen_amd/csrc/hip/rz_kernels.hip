@@ -150,13 +150,14 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
 // Waves per SIMD asked of the compiler (the kernel is issue-bound: another resident wave overlaps scalar / VMEM / LDS
 // issue with VALU).  Measured on C2: 2 -> 29.0 ms, 3 -> 22.1 ms; 4 paid off only once the SLP vectoriser was switched
 // off (build.py: it paired f32 ops into 64-bit register tuples and cost 25 VGPRs): 142 VGPRs -> 128 with 13 spilled,
-// 18.65 -> 17.65 ms.  The transparent variant keeps 3: its 13.6 KB of LDS per wave caps occupancy first, and at 128
-// VGPRs it spills 28 (measured 49.4 -> 54.3 ms at 4).
+// 18.65 -> 17.65 ms.  The transparent variant first stayed at 3 (its LDS capped occupancy at 11 waves per CU, so the
+// 28 registers spilled at 128 VGPRs bought nothing: 49.4 -> 54.3 ms); with the BLAS stack cut to an LDS window
+// (rz_context.hip: render_samples) 16 waves fit and 4 wins: 40.2 -> 34.3 ms.
 #ifndef RZ_SAMPLES_MIN_WAVES
 #define RZ_SAMPLES_MIN_WAVES 4
 #endif
 #ifndef RZ_SAMPLES_MIN_WAVES_GLASS
-#define RZ_SAMPLES_MIN_WAVES_GLASS 3
+#define RZ_SAMPLES_MIN_WAVES_GLASS 4
 #endif
 __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
     a.traversals += b.traversals; a.tlas_nodes += b.tlas_nodes; a.tlas_leaf_indices += b.tlas_leaf_indices;
