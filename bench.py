@@ -173,7 +173,7 @@ def main():
                            "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic,
                            "note": "achieved = ALGORITHMIC bytes (what RayZen's shader reads from its SSBOs for this "
                                    "frame, counted exactly) / kernel time; the 6 MB scene is L1/L2/scalar-cache "
-                                   "resident, so measured HBM traffic is ~240x smaller and frac may exceed 1: HBM is "
+                                   "resident, so measured HBM traffic is ~230x smaller and frac may exceed 1: HBM is "
                                    "not what bounds this kernel (VALU issue is: see DESIGN.md section 4.7)",
                            "kernel": r.last_kernel_name(), "kernel_ms": round(kms, 3),
                            "algorithmic_bytes_per_launch": int(alg_bytes),

@@ -491,7 +491,10 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
 #ifndef RZ_GLASS_WAVES_PER_CU
 #define RZ_GLASS_WAVES_PER_CU 16
 #endif
-    const size_t budget = (size_t)160 * 1024 / (c->sceneHasTransparency ? RZ_GLASS_WAVES_PER_CU : 16);
+#ifndef RZ_OPAQUE_WAVES_PER_CU
+#define RZ_OPAQUE_WAVES_PER_CU 16
+#endif
+    const size_t budget = (size_t)160 * 1024 / (c->sceneHasTransparency ? RZ_GLASS_WAVES_PER_CU : RZ_OPAQUE_WAVES_PER_CU);
     const size_t fixed = samples_lds_extra(c->sceneHasTransparency) + (size_t)K.tlasStackCap * 256;
     int window = budget > fixed ? (int)((budget - fixed) / 512) : 0;
     if (const char* e = std::getenv("RZ_BLAS_STACK_WINDOW")) window = std::atoi(e);        // test aid: force a small window
