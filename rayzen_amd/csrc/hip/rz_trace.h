@@ -135,11 +135,18 @@ __device__ __forceinline__ bool moller_trumbore(v3 o, v3 d, v3 v0, v3 e1, v3 e2,
     float f = 1.0f / a;
     v3 s = o - v0;
     float u = f * dot(s, h);
+    bool ok = !(__builtin_fabsf(a) < 0.0001f);
+    ok = ok && !(u < 0.0f || u > 1.0f);
+#ifndef RZ_NO_TRI_EARLY_OUT
+    // Wave-level early out after the shader's second test: the lanes of a wave are mostly samples of one pixel testing
+    // the same triangle with near-identical rays, so they tend to fail together -- and then the second cross product,
+    // two dot products and the remaining comparisons (about 30 of the test's 75 instructions) are skipped.  A lane's
+    // own result is unchanged: values computed past a failed test were never used.
+    if (__ballot(ok) == 0ull) return false;
+#endif
     v3 q = cross(s, e1);
     float v = f * dot(d, q);
     t = f * dot(e2, q);
-    bool ok = !(__builtin_fabsf(a) < 0.0001f);
-    ok = ok && !(u < 0.0f || u > 1.0f);
     ok = ok && !(v < 0.0f || u + v > 1.0f);
     return ok && (t > 0.0001f);
 }
