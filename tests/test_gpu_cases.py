@@ -370,3 +370,22 @@ def test_blas_stack_overflow_columns_give_the_same_frame(window, monkeypatch):
     o = np.zeros_like(got)
     rzo.render(oracle_scene(sc), oracle_frame(sc, W, H, spp, b), accum=o, crop=(0, y0, W, y0 + 8), nthreads=16)
     assert (got[y0:y0 + 8].view(np.uint32) == o[y0:y0 + 8].view(np.uint32)).all()
+
+
+def test_persistent_launch_glass_scene_chunked_and_windowed(monkeypatch):
+    """The persistent-wave launch (large frame, spp >= 64) of the speculating kernel: 128 spp in one call, as two
+    continued calls of 64 (currentIor carried through K.ior), and with a 3-entry LDS stack window -- one frame."""
+    sc = S.bunny_scene(n=16, aspect=1280 / 1024, extras=True)
+    W, H, b = 1280, 1024, 5
+    one = hip_render(sc, W, H, 128, b)
+    two = hip_render(sc, W, H, 128, b, chunk=64)
+    assert (one.view(np.uint32) == two.view(np.uint32)).all(), mismatch_report(two, one)
+    monkeypatch.setenv("RZ_BLAS_STACK_WINDOW", "3")
+    win = hip_render(sc, W, H, 128, b)
+    assert (one.view(np.uint32) == win.view(np.uint32)).all(), mismatch_report(win, one)
+    y0 = 400
+    from helpers import oracle_frame, oracle_scene
+    from oracle import rzo
+    o = np.zeros_like(one)
+    rzo.render(oracle_scene(sc), oracle_frame(sc, W, H, 128, b), accum=o, crop=(0, y0, W, y0 + 8), nthreads=16)
+    assert (one[y0:y0 + 8].view(np.uint32) == o[y0:y0 + 8].view(np.uint32)).all()
