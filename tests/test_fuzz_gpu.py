@@ -1,6 +1,8 @@
 """Seeded random scenes through both implementations: random materials (several transparent ones with different
 ior, mirrors, rough metals), point and directional lights (some axis-aligned: 1/0 in the slab test), instances under
 rotation / non-uniform scale / mirroring, random cameras, 1..40 spp, 1..8 bounces.  HIP == oracle bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -59,7 +61,10 @@ def random_scene(seed):
     return s.build(share_meshes=bool(rng.integers(0, 2))), rng
 
 
-@pytest.mark.parametrize("seed", range(64))
+N_SMALL = int(os.environ.get("RZ_FUZZ_SEEDS", "64"))      # a one-off soak can ask for more
+
+
+@pytest.mark.parametrize("seed", range(N_SMALL))
 def test_random_scene(seed):
     sc, rng = random_scene(1000 + seed)
     W, H = int(rng.integers(17, 97)), int(rng.integers(9, 65))
