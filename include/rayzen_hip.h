@@ -98,7 +98,8 @@ typedef enum rz_status {
     RZ_ERR_OUT_OF_RANGE   = -4,  /* rz_update past the end of a binding */
     RZ_ERR_NOT_READY      = -5,  /* render before all bindings / frame set */
     RZ_ERR_BAD_SCENE      = -6,  /* uploaded arrays are inconsistent */
-    RZ_ERR_BUFFER_SIZE    = -7   /* caller buffer too small */
+    RZ_ERR_BUFFER_SIZE    = -7,  /* caller buffer too small */
+    RZ_ERR_NO_MEMORY      = -8   /* a host allocation failed inside the library (std::bad_alloc never crosses the ABI) */
 } rz_status;
 
 /* Per-frame parameters = the uniforms of sendSceneDataToShader
@@ -185,7 +186,8 @@ int rz_build_blas(rz_ctx* ctx, const rz_triangle* tris, size_t n, rz_bvh_node* n
  * instances / TLAS nodes / TLAS indices the device built).  out == NULL: only *needed is set. */
 int rz_read_binding(rz_ctx* ctx, rz_binding binding, void* out, size_t bytes, size_t* needed);
 
-/* glUniform* in sendSceneDataToShader (main.cpp:1356-1379). */
+/* glUniform* in sendSceneDataToShader (main.cpp:1356-1379).  A change of resolution or of the tile assignment
+ * (tile_rank / tile_nranks) zeroes the whole accumulation buffer: pixels a context does not own always read as zero. */
 int rz_set_frame(rz_ctx* ctx, const rz_frame_params* params);
 
 /* Optional plumbing for a caller that owns the device memory and the stream
@@ -255,6 +257,67 @@ const char* rz_last_kernel_name(const rz_ctx* ctx);
 
 /* Device pointer of the accumulation buffer currently in use. */
 void* rz_accum_device_ptr(rz_ctx* ctx);
+
+/* TEST HOOK: make the nth host-side allocation site reached from now on (scene re-layout, upload copies, staging
+ * vectors) fail as if memory had run out; the call in progress returns RZ_ERR_NO_MEMORY and the context stays usable.
+ * nth <= 0 disarms. */
+int rz_debug_fail_alloc(rz_ctx* ctx, int nth);
+
+/* The HIP stream (hipStream_t) the context's work is enqueued on. */
+void* rz_stream_handle(rz_ctx* ctx);
+
+/* ------------------------------------------------------------------------ */
+/* Multi-GPU group: tile-sharded rendering + ONE RCCL reduce per frame.       */
+/* ------------------------------------------------------------------------ */
+/* The reference is single-GPU: its context lifetime is glfwCreateWindow / glfwMakeContextCurrent (main.cpp:228-241)
+ * and the teardown at main.cpp:681-686.  A group is that lifetime for N GPUs of one node: it owns one rz_ctx per LOCAL
+ * device and the RCCL communicator(s), gives member m the tiles t with t % nranks == rank(m) (rz_frame_params.tile_rank
+ * / tile_nranks are filled in by the group), and lands the frame on the root rank with ONE ncclReduce(SUM) of the
+ * RGBA32F accumulation buffer over xGMI, issued on the members' render streams (no host synchronisation between the
+ * render kernel and the collective).  Tile sets are disjoint and non-owned pixels are zero, so the sum adds each
+ * pixel's single value to zeros: the reduced frame is bit-identical to a single-GPU frame.
+ *
+ * Two ways to form a group:
+ *   rz_group_create       one process drives ndev devices (ncclCommInitAll); ranks = 0..ndev-1, all local.
+ *   rz_group_create_rank  one process per GPU (the usual launcher layout): every process passes its own device, its
+ *                         rank, the group size and the 128-byte id that rank 0 obtained from rz_group_unique_id and
+ *                         distributed by whatever channel the launcher has (ncclCommInitRank; blocks until all ranks
+ *                         have called it).
+ * RCCL is bound at run time, when the first group is created (librayzen_hip.so has no link-time dependency on the
+ * 570-MB librccl, so single-GPU users never load it): an RCCL already loaded in the process is reused, else
+ * $RZ_RCCL_LIBRARY, else /opt/rocm/lib/librccl.so.1.  rz_group_rccl_version() reports what was bound (no GPU needed). */
+typedef struct rz_group rz_group;
+#define RZ_GROUP_ID_BYTES 128
+int       rz_group_rccl_version(int* version);                 /* binds RCCL; *version = ncclGetVersion() */
+int       rz_group_unique_id(void* id128);                      /* ncclGetUniqueId into RZ_GROUP_ID_BYTES bytes */
+rz_group* rz_group_create(int ndev, const int* devices, unsigned flags);        /* devices NULL: 0..ndev-1 */
+rz_group* rz_group_create_rank(int device, int rank, int nranks, const void* id128, unsigned flags);
+void      rz_group_destroy(rz_group* g);
+const char* rz_group_last_error(const rz_group* g);             /* g NULL: the error of a failed create */
+int       rz_group_size(const rz_group* g);                     /* ranks in the communicator */
+int       rz_group_local_count(const rz_group* g);              /* members owned by this process */
+int       rz_group_rank(const rz_group* g, int local);          /* global rank of local member `local` */
+rz_ctx*   rz_group_ctx(rz_group* g, int local);                 /* the member's context (for per-device calls) */
+/* glBufferData / glBufferSubData on every local member (the scene is replicated: <= 88 MB even for configs[4]). */
+int rz_group_upload(rz_group* g, rz_binding binding, const void* data, size_t bytes);
+int rz_group_update(rz_group* g, rz_binding binding, size_t offset, const void* data, size_t bytes);
+/* sendSceneDataToShader for every local member; tile_rank / tile_nranks of *params are ignored and set per member. */
+int rz_group_set_frame(rz_group* g, const rz_frame_params* params);
+/* glDrawArrays on every local member: asynchronous, each on its own device and stream. */
+int rz_group_render(rz_group* g);
+/* ONE ncclReduce(sum, float, width*height*4) per member, enqueued on the member's stream behind its render kernel,
+ * from the member's accumulation buffer into the root member's frame buffer (out of place: nobody's accumulation
+ * buffer is overwritten, so frames can be continued with sample_base > 0). */
+int rz_group_reduce(rz_group* g, int root);
+int rz_group_sync(rz_group* g);                                 /* glFinish on every local member */
+/* Copy the reduced frame (RGBA32F, row 0 = bottom) to host memory.  Only valid in the process that owns `root` of the
+ * last rz_group_reduce; RZ_ERR_NOT_READY elsewhere.  Synchronises that member's stream. */
+int rz_group_read_frame(rz_group* g, float* rgba, size_t bytes);
+/* Device pointer of the reduced frame on the root member (NULL in other processes). */
+void* rz_group_frame_device_ptr(rz_group* g);
+
+/* Number of HIP devices visible to the process (0 without a GPU). */
+int rz_device_count(void);
 
 /* Library/version probe that needs no GPU. */
 const char* rz_version(void);

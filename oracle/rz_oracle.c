@@ -459,17 +459,25 @@ static void shade_pixel(rctx* c, const rzo_frame* fr, int px, int py, float* acc
 typedef struct {
     const rzo_scene* sc; const rzo_frame* fr; float* accum; float* ior_state;
     int x0, y0, x1, y1;
-    volatile int* next_row;
+    volatile long long* next_chunk;
     rzo_counters cnt;
+    long long pixels_done;
 } job_t;
+
+/* Work is handed out in chunks of RZO_CHUNK consecutive pixels of the crop rectangle (row-major), not in rows: a
+ * short, wide crop (the benchmark's 8-row bands) must still keep every thread busy. */
+#define RZO_CHUNK 16
 
 static void* worker(void* arg) {
     job_t* j = (job_t*)arg;
     rctx c; c.sc = j->sc; memset(&c.cnt, 0, sizeof c.cnt);
+    const long long w = j->x1 - j->x0, total = w * (long long)(j->y1 - j->y0);
     for (;;) {
-        int y = __sync_fetch_and_add(j->next_row, 1);
-        if (y >= j->y1) break;
-        for (int x = j->x0; x < j->x1; ++x) {
+        long long k0 = __sync_fetch_and_add(j->next_chunk, (long long)RZO_CHUNK);
+        if (k0 >= total) break;
+        long long k1 = k0 + RZO_CHUNK < total ? k0 + RZO_CHUNK : total;
+        for (long long k = k0; k < k1; ++k) {
+            const int y = j->y0 + (int)(k / w), x = j->x0 + (int)(k % w);
             size_t p = (size_t)y * j->fr->width + x;
             float* acc = j->accum + 4 * p;
             float ior = 1.0f;
@@ -478,11 +486,15 @@ static void* worker(void* arg) {
             shade_pixel(&c, j->fr, x, y, acc, &ior);
             if (j->ior_state) j->ior_state[p] = ior;
             c.cnt.pixels++;
+            j->pixels_done++;
         }
     }
     j->cnt = c.cnt;
     return NULL;
 }
+
+static int g_threads_busy = 0;
+int rzo_last_threads_busy(void) { return g_threads_busy; }
 
 int rzo_render(const rzo_scene* scene, const rzo_frame* frame, float* accum, float* ior_state,
                int x0, int y0, int x1, int y1, int nthreads, rzo_counters* counters) {
@@ -493,18 +505,21 @@ int rzo_render(const rzo_scene* scene, const rzo_frame* frame, float* accum, flo
     if (y1 > frame->height) y1 = frame->height;
     if (nthreads <= 0) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
-    volatile int next_row = y0;
+    volatile long long next_chunk = 0;
+    if (x1 <= x0 || y1 <= y0) { if (counters) memset(counters, 0, sizeof *counters); return 0; }
     job_t* jobs = (job_t*)calloc((size_t)nthreads, sizeof(job_t));
     pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
     for (int i = 0; i < nthreads; ++i) {
         jobs[i].sc = scene; jobs[i].fr = frame; jobs[i].accum = accum; jobs[i].ior_state = ior_state;
-        jobs[i].x0 = x0; jobs[i].y0 = y0; jobs[i].x1 = x1; jobs[i].y1 = y1; jobs[i].next_row = &next_row;
+        jobs[i].x0 = x0; jobs[i].y0 = y0; jobs[i].x1 = x1; jobs[i].y1 = y1; jobs[i].next_chunk = &next_chunk;
     }
     if (nthreads == 1) worker(&jobs[0]);
     else {
         for (int i = 0; i < nthreads; ++i) pthread_create(&th[i], NULL, worker, &jobs[i]);
         for (int i = 0; i < nthreads; ++i) pthread_join(th[i], NULL);
     }
+    g_threads_busy = 0;
+    for (int i = 0; i < nthreads; ++i) g_threads_busy += jobs[i].pixels_done > 0;
     if (counters) {
         memset(counters, 0, sizeof *counters);
         for (int i = 0; i < nthreads; ++i) {

@@ -74,6 +74,9 @@ typedef struct {
 int rzo_render(const rzo_scene* scene, const rzo_frame* frame, float* accum, float* ior_state,
                int x0, int y0, int x1, int y1, int nthreads, rzo_counters* counters);
 
+/* How many of the last rzo_render call's threads rendered at least one pixel (work is handed out in 16-pixel chunks). */
+int rzo_last_threads_busy(void);
+
 /* One closest-hit query (FS:457-503), for known-answer tests.
  * out = {hit(0/1), t, px,py,pz, nx,ny,nz, materialIndex, instanceIdx}. */
 int rzo_trace(const rzo_scene* scene, const float origin[3], const float dir[3], float out[10]);

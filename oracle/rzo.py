@@ -78,6 +78,8 @@ def lib():
         L.rzo_render.restype = C.c_int
         L.rzo_render.argtypes = [C.POINTER(_Scene), C.POINTER(_Frame), C.c_void_p, C.c_void_p,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_Counters)]
+        L.rzo_last_threads_busy.restype = C.c_int
+        L.rzo_last_threads_busy.argtypes = []
         L.rzo_present.restype = C.c_int
         L.rzo_present.argtypes = [C.POINTER(_Scene), C.POINTER(_Present), C.c_void_p, C.c_void_p, C.c_void_p]
         L.rzo_trace.restype = C.c_int
@@ -153,6 +155,11 @@ def render(scene, frame, accum=None, ior_state=None, crop=None, nthreads=1, want
     if want_counters:
         return accum, {n: int(getattr(cnt, n)) for n in COUNTER_FIELDS}
     return accum
+
+
+def last_threads_busy():
+    """Threads of the last render() call that rendered at least one pixel."""
+    return int(lib().rzo_last_threads_busy())
 
 
 def present(scene, accum, view, proj, num_lights, fps=0.0, show_fps=True, show_lights=False, show_bvh=False,

@@ -16,6 +16,11 @@ HIP_SYMBOLS = (
     "rz_set_frame", "rz_set_stream",
     "rz_bind_accum", "rz_render", "rz_render_counted", "rz_sync", "rz_clear_accum", "rz_read_accum",
     "rz_resolve_rgba8", "rz_present", "rz_last_render_ms", "rz_render_history_ms", "rz_last_kernel_name", "rz_accum_device_ptr", "rz_version", "rz_sizeof",
+    "rz_debug_fail_alloc", "rz_stream_handle", "rz_device_count",
+    "rz_group_rccl_version", "rz_group_unique_id", "rz_group_create", "rz_group_create_rank", "rz_group_destroy",
+    "rz_group_last_error", "rz_group_size", "rz_group_local_count", "rz_group_rank", "rz_group_ctx", "rz_group_upload",
+    "rz_group_update", "rz_group_set_frame", "rz_group_render", "rz_group_reduce", "rz_group_sync", "rz_group_read_frame",
+    "rz_group_frame_device_ptr",
 )
 # the symbols include/rayzen_host.h declares
 HOST_SYMBOLS = (
@@ -91,6 +96,27 @@ def hip():
         L.rz_accum_device_ptr.restype, L.rz_accum_device_ptr.argtypes = vp, [vp]
         L.rz_version.restype, L.rz_version.argtypes = C.c_char_p, []
         L.rz_sizeof.restype, L.rz_sizeof.argtypes = sz, [i]
+        L.rz_debug_fail_alloc.restype, L.rz_debug_fail_alloc.argtypes = i, [vp, i]
+        L.rz_stream_handle.restype, L.rz_stream_handle.argtypes = vp, [vp]
+        L.rz_device_count.restype, L.rz_device_count.argtypes = i, []
+        L.rz_group_rccl_version.restype, L.rz_group_rccl_version.argtypes = i, [C.POINTER(i)]
+        L.rz_group_unique_id.restype, L.rz_group_unique_id.argtypes = i, [vp]
+        L.rz_group_create.restype, L.rz_group_create.argtypes = vp, [i, C.POINTER(i), C.c_uint]
+        L.rz_group_create_rank.restype, L.rz_group_create_rank.argtypes = vp, [i, i, i, vp, C.c_uint]
+        L.rz_group_destroy.restype, L.rz_group_destroy.argtypes = None, [vp]
+        L.rz_group_last_error.restype, L.rz_group_last_error.argtypes = C.c_char_p, [vp]
+        L.rz_group_size.restype, L.rz_group_size.argtypes = i, [vp]
+        L.rz_group_local_count.restype, L.rz_group_local_count.argtypes = i, [vp]
+        L.rz_group_rank.restype, L.rz_group_rank.argtypes = i, [vp, i]
+        L.rz_group_ctx.restype, L.rz_group_ctx.argtypes = vp, [vp, i]
+        L.rz_group_upload.restype, L.rz_group_upload.argtypes = i, [vp, i, vp, sz]
+        L.rz_group_update.restype, L.rz_group_update.argtypes = i, [vp, i, sz, vp, sz]
+        L.rz_group_set_frame.restype, L.rz_group_set_frame.argtypes = i, [vp, C.POINTER(FrameParams)]
+        L.rz_group_render.restype, L.rz_group_render.argtypes = i, [vp]
+        L.rz_group_reduce.restype, L.rz_group_reduce.argtypes = i, [vp, i]
+        L.rz_group_sync.restype, L.rz_group_sync.argtypes = i, [vp]
+        L.rz_group_read_frame.restype, L.rz_group_read_frame.argtypes = i, [vp, vp, sz]
+        L.rz_group_frame_device_ptr.restype, L.rz_group_frame_device_ptr.argtypes = vp, [vp]
         _hip = L
     return _hip
 

@@ -55,7 +55,7 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     deps = srcs + _files(HIP_DIR, (".h",)) + _files(INC, (".h",)) + [os.path.abspath(__file__)]
     if not force and not _newer(HIP_SO, deps):
         return HIP_SO
-    cmd = [hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + ["-I", INC, "-I", HIP_DIR, "-shared", "-o", HIP_SO] + srcs
+    cmd = [hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + ["-I", INC, "-I", HIP_DIR, "-shared", "-o", HIP_SO] + srcs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

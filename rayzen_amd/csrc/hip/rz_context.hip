@@ -139,6 +139,7 @@ struct rz_ctx {
     const char* lastKernel = "";
     void* extAccum = nullptr;
     size_t extAccumBytes = 0;
+    int failAllocCountdown = 0;         // rz_debug_fail_alloc (test hook)
 };
 
 namespace {
@@ -149,9 +150,31 @@ int fail(rz_ctx* c, int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (c) c->err = buf;
-    g_last_error = buf;
+    try {
+        if (c) c->err = buf;
+        g_last_error = buf;
+    } catch (...) { }     // the code still tells the caller what happened
     return code;
+}
+
+// No C++ exception crosses the C-ABI: every exported entry point that can reach a std::vector / std::map /
+// std::string growth runs its body through guarded(), which turns std::bad_alloc into RZ_ERR_NO_MEMORY and anything
+// else into RZ_ERR_HIP.  (rz_debug_fail_alloc arms a countdown that makes alloc_point() throw std::bad_alloc at the
+// n-th host allocation site reached -- the test hook that proves the conversion.)
+template <class F>
+int guarded(rz_ctx* c, const char* what, F&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(c, RZ_ERR_NO_MEMORY, "%s: out of host memory", what);
+    } catch (const std::exception& e) {
+        return fail(c, RZ_ERR_HIP, "%s: %s", what, e.what());
+    } catch (...) {
+        return fail(c, RZ_ERR_HIP, "%s: unknown C++ exception", what);
+    }
+}
+void alloc_point(rz_ctx* c) {
+    if (c->failAllocCountdown > 0 && --c->failAllocCountdown == 0) throw std::bad_alloc();
 }
 
 #define RZ_HIP(c, call)                                                                            \
@@ -246,6 +269,7 @@ int build_view(rz_ctx* c, int nodeOff, int triOff, int gTriOff, BlasView& V) {
                     queue.push_back({chIdx[k], it.depth + 1});
                 }
             }
+            alloc_point(c);
             c->hPairs.push_back(P);
         }
         // queue[i] is the i-th internal node in BFS order and its pair was pushed i-th: enc == i holds by construction
@@ -261,6 +285,7 @@ int build_view(rz_ctx* c, int nodeOff, int triOff, int gTriOff, BlasView& V) {
         d.e2x = t.v2[0] - t.v0[0]; d.e2y = t.v2[1] - t.v0[1]; d.e2z = t.v2[2] - t.v0[2];   // FS:393
         d.mat = t.materialIndex;
         d.src = (int32_t)src;
+        if ((s & 1023) == 0) alloc_point(c);
         c->hTris.push_back(d);
     }
     return RZ_OK;
@@ -304,7 +329,7 @@ int tlas_depth(const rz_bvh_node* n, size_t count) {
     return best;
 }
 
-int finalize(rz_ctx* c) {
+int finalize_body(rz_ctx* c) {
     if (!(c->geomDirty || c->instDirty || c->tlasDirty || c->matDirty || c->lightDirty)) return RZ_OK;
     for (int b : {RZ_BIND_TRIANGLES, RZ_BIND_MATERIALS, RZ_BIND_LIGHTS, RZ_BIND_TLAS_NODES, RZ_BIND_TLAS_INDICES,
                   RZ_BIND_BLAS_NODES, RZ_BIND_BLAS_INDICES, RZ_BIND_INSTANCES})
@@ -314,6 +339,7 @@ int finalize(rz_ctx* c) {
     if (c->instDirty) {
         const rz_bvh_instance* inst = hostArr<rz_bvh_instance>(c, RZ_BIND_INSTANCES);
         const size_t nInst = hostCount<rz_bvh_instance>(c, RZ_BIND_INSTANCES);
+        alloc_point(c);
         std::vector<DevInstance> dev(nInst);
         bool grew = false;
         c->maxBlasDepth = 1;
@@ -402,6 +428,18 @@ int finalize(rz_ctx* c) {
     RZ_HIP(c, hipStreamSynchronize(c->stream));
     c->geomDirty = c->instDirty = c->tlasDirty = c->matDirty = c->lightDirty = false;
     return RZ_OK;
+}
+
+// A failure half-way through the re-layout (an exception from a growing vector) must not leave a half-built scene
+// behind: drop the derived state, keep the caller's arrays, and let the next call redo it.
+int finalize(rz_ctx* c) {
+    try {
+        return finalize_body(c);
+    } catch (...) {
+        c->views.clear(); c->hPairs.clear(); c->hTris.clear();
+        c->geomDirty = true;
+        throw;
+    }
 }
 
 constexpr int kWfMaxRounds = 16384;
@@ -618,7 +656,12 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
 
 extern "C" {
 
-const char* rz_version(void) { return "rayzen_hip 0.1 (gfx950)"; }
+const char* rz_version(void) { return "rayzen_hip 0.2 (gfx950)"; }
+
+int rz_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
 
 size_t rz_sizeof(int which) {
     switch (which) {
@@ -674,16 +717,15 @@ void rz_destroy(rz_ctx* c) {
     delete c;
 }
 
-int rz_upload(rz_ctx* c, rz_binding binding, const void* data, size_t bytes) {
+static int upload_impl(rz_ctx* c, rz_binding binding, const void* data, size_t bytes) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
     const size_t es = elem_size((int)binding);
     if (es == 0) return fail(c, RZ_ERR_INVALID_ARG, "unknown binding %d", (int)binding);
     if (bytes % es) return fail(c, RZ_ERR_INVALID_ARG, "binding %d: %zu bytes is not a multiple of the %zu-byte element", (int)binding, bytes, es);
     if (bytes && !data) return fail(c, RZ_ERR_INVALID_ARG, "null data");
     if (c->deviceOwnsTlas) { int rc = sync_host_from_device(c); if (rc != RZ_OK) return rc; }
-    try {
-        c->host[binding].assign(static_cast<const unsigned char*>(data), static_cast<const unsigned char*>(data) + bytes);
-    } catch (...) { return fail(c, RZ_ERR_HIP, "out of host memory"); }
+    alloc_point(c);
+    c->host[binding].assign(static_cast<const unsigned char*>(data), static_cast<const unsigned char*>(data) + bytes);
     c->present[binding] = true;
     switch (binding) {
         case RZ_BIND_MATERIALS: c->matDirty = true; break;
@@ -695,7 +737,7 @@ int rz_upload(rz_ctx* c, rz_binding binding, const void* data, size_t bytes) {
     return RZ_OK;
 }
 
-int rz_update(rz_ctx* c, rz_binding binding, size_t offset, const void* data, size_t bytes) {
+static int update_impl(rz_ctx* c, rz_binding binding, size_t offset, const void* data, size_t bytes) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
     if (elem_size((int)binding) == 0) return fail(c, RZ_ERR_INVALID_ARG, "unknown binding %d", (int)binding);
     if (!c->present[binding]) return fail(c, RZ_ERR_NOT_READY, "binding %d has not been uploaded", (int)binding);
@@ -716,7 +758,7 @@ int rz_update(rz_ctx* c, rz_binding binding, size_t offset, const void* data, si
     return RZ_OK;
 }
 
-int rz_update_transforms(rz_ctx* c, const float* transforms, size_t n) {
+static int update_transforms_impl(rz_ctx* c, const float* transforms, size_t n) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
     if (!transforms && n) return fail(c, RZ_ERR_INVALID_ARG, "null transforms");
     RZ_HIP(c, hipSetDevice(c->device));
@@ -766,7 +808,7 @@ int rz_update_transforms(rz_ctx* c, const float* transforms, size_t n) {
     return RZ_OK;
 }
 
-int rz_build_blas(rz_ctx* c, const rz_triangle* tris, size_t n, rz_bvh_node* nodes_out, size_t nodes_cap, int32_t* indices_out,
+static int build_blas_impl(rz_ctx* c, const rz_triangle* tris, size_t n, rz_bvh_node* nodes_out, size_t nodes_cap, int32_t* indices_out,
                   size_t* n_nodes, int* depth, float* device_ms) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
     if (n && !tris) return fail(c, RZ_ERR_INVALID_ARG, "null triangles");
@@ -789,7 +831,8 @@ int rz_build_blas(rz_ctx* c, const rz_triangle* tris, size_t n, rz_bvh_node* nod
     int rc = ensure(c, c->dBuildWs, ws);
     if (rc != RZ_OK) return rc;
     std::vector<rz_bvh_node> tmp;
-    try { tmp.resize(2 * n + 2); } catch (...) { return fail(c, RZ_ERR_HIP, "out of host memory"); }
+    alloc_point(c);
+    tmp.resize(2 * n + 2);
     int nn = 0, dp = 0;
     const int e = blas_build_device(tris, n, c->dBuildWs.p, c->dBuildWs.cap, tmp.data(), indices_out, &nn, &dp, device_ms, c->stream);
     if (e > 0) return fail(c, RZ_ERR_HIP, "device BLAS build: %s", hipGetErrorString((hipError_t)e));
@@ -801,7 +844,7 @@ int rz_build_blas(rz_ctx* c, const rz_triangle* tris, size_t n, rz_bvh_node* nod
     return RZ_OK;
 }
 
-int rz_read_binding(rz_ctx* c, rz_binding binding, void* out, size_t bytes, size_t* needed) {
+static int read_binding_impl(rz_ctx* c, rz_binding binding, void* out, size_t bytes, size_t* needed) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
     if (elem_size((int)binding) == 0) return fail(c, RZ_ERR_INVALID_ARG, "unknown binding %d", (int)binding);
     if (!c->present[binding]) return fail(c, RZ_ERR_NOT_READY, "binding %d has not been uploaded", (int)binding);
@@ -814,7 +857,7 @@ int rz_read_binding(rz_ctx* c, rz_binding binding, void* out, size_t bytes, size
     return RZ_OK;
 }
 
-int rz_set_frame(rz_ctx* c, const rz_frame_params* p) {
+static int set_frame_impl(rz_ctx* c, const rz_frame_params* p) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
     if (!p) return fail(c, RZ_ERR_INVALID_ARG, "null params");
     if (p->width <= 0 || p->height <= 0 || (long long)p->width * p->height > (1ll << 28))
@@ -835,6 +878,12 @@ int rz_set_frame(rz_ctx* c, const rz_frame_params* p) {
             RZ_HIP(c, hipMemsetAsync(c->ownAccum.p, 0, nPix * 16, c->stream));
         }
     }
+    // a different tile assignment: pixels this context owned before and no longer owns must read as zero again
+    // (the group's reduce sums every member's whole buffer)
+    if (!resized && c->haveFrame && (c->frame.tile_rank != p->tile_rank || c->frame.tile_nranks != p->tile_nranks)) {
+        void* acc = c->extAccum ? c->extAccum : c->ownAccum.p;
+        if (acc && (!c->extAccum || c->extAccumBytes >= nPix * 16)) RZ_HIP(c, hipMemsetAsync(acc, 0, nPix * 16, c->stream));
+    }
     c->frame = *p;
     c->haveFrame = true;
     return RZ_OK;
@@ -847,7 +896,7 @@ int rz_set_stream(rz_ctx* c, void* hip_stream) {
     return RZ_OK;
 }
 
-int rz_bind_accum(rz_ctx* c, void* device_rgba, size_t bytes) {
+static int bind_accum_impl(rz_ctx* c, void* device_rgba, size_t bytes) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
     c->extAccum = device_rgba;
     c->extAccumBytes = device_rgba ? bytes : 0;
@@ -861,8 +910,12 @@ int rz_bind_accum(rz_ctx* c, void* device_rgba, size_t bytes) {
     return RZ_OK;
 }
 
-int rz_render(rz_ctx* c) { return do_render(c, false, nullptr); }
-int rz_render_counted(rz_ctx* c, rz_counters* out) { return do_render(c, true, out); }
+int rz_render(rz_ctx* c) {
+    return guarded(c, "rz_render", [&] { return do_render(c, false, nullptr); });
+}
+int rz_render_counted(rz_ctx* c, rz_counters* out) {
+    return guarded(c, "rz_render_counted", [&] { return do_render(c, true, out); });
+}
 
 int rz_sync(rz_ctx* c) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
@@ -870,12 +923,14 @@ int rz_sync(rz_ctx* c) {
     return RZ_OK;
 }
 
+void* rz_stream_handle(rz_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
 void* rz_accum_device_ptr(rz_ctx* c) {
     if (!c) return nullptr;
     return c->extAccum ? c->extAccum : c->ownAccum.p;
 }
 
-int rz_clear_accum(rz_ctx* c) {
+static int clear_accum_impl(rz_ctx* c) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
     if (!c->haveFrame) return fail(c, RZ_ERR_NOT_READY, "rz_set_frame has not been called");
     void* p = rz_accum_device_ptr(c);
@@ -883,7 +938,7 @@ int rz_clear_accum(rz_ctx* c) {
     return RZ_OK;
 }
 
-int rz_read_accum(rz_ctx* c, float* rgba, size_t bytes) {
+static int read_accum_impl(rz_ctx* c, float* rgba, size_t bytes) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
     if (!c->haveFrame) return fail(c, RZ_ERR_NOT_READY, "rz_set_frame has not been called");
     const size_t need = (size_t)c->frame.width * c->frame.height * 16;
@@ -893,7 +948,7 @@ int rz_read_accum(rz_ctx* c, float* rgba, size_t bytes) {
     return RZ_OK;
 }
 
-int rz_resolve_rgba8(rz_ctx* c, uint8_t* rgba8, size_t bytes) {
+static int resolve_rgba8_impl(rz_ctx* c, uint8_t* rgba8, size_t bytes) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
     if (!c->haveFrame) return fail(c, RZ_ERR_NOT_READY, "rz_set_frame has not been called");
     const size_t nPix = (size_t)c->frame.width * c->frame.height;
@@ -907,7 +962,7 @@ int rz_resolve_rgba8(rz_ctx* c, uint8_t* rgba8, size_t bytes) {
     return RZ_OK;
 }
 
-int rz_present(rz_ctx* c, const rz_present_params* pp, uint8_t* rgba8, size_t rgba8_bytes, float* rgb32f, size_t rgb32f_bytes) {
+static int present_impl(rz_ctx* c, const rz_present_params* pp, uint8_t* rgba8, size_t rgba8_bytes, float* rgb32f, size_t rgb32f_bytes) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
     if (!pp) return fail(c, RZ_ERR_INVALID_ARG, "null params");
     if (!c->haveFrame) return fail(c, RZ_ERR_NOT_READY, "rz_set_frame has not been called");
@@ -1018,6 +1073,47 @@ int rz_render_history_ms(rz_ctx* c, float* ms, int cap) {
     }
     c->ringCount = 0;
     return n;
+}
+
+// ---- exported wrappers: no exception leaves the library (guarded(), above) ----
+int rz_upload(rz_ctx* c, rz_binding binding, const void* data, size_t bytes) {
+    return guarded(c, "rz_upload", [&] { return upload_impl(c, binding, data, bytes); });
+}
+int rz_update(rz_ctx* c, rz_binding binding, size_t offset, const void* data, size_t bytes) {
+    return guarded(c, "rz_update", [&] { return update_impl(c, binding, offset, data, bytes); });
+}
+int rz_update_transforms(rz_ctx* c, const float* transforms, size_t n) {
+    return guarded(c, "rz_update_transforms", [&] { return update_transforms_impl(c, transforms, n); });
+}
+int rz_build_blas(rz_ctx* c, const rz_triangle* tris, size_t n, rz_bvh_node* nodes_out, size_t nodes_cap, int32_t* indices_out, size_t* n_nodes, int* depth, float* device_ms) {
+    return guarded(c, "rz_build_blas", [&] { return build_blas_impl(c, tris, n, nodes_out, nodes_cap, indices_out, n_nodes, depth, device_ms); });
+}
+int rz_read_binding(rz_ctx* c, rz_binding binding, void* out, size_t bytes, size_t* needed) {
+    return guarded(c, "rz_read_binding", [&] { return read_binding_impl(c, binding, out, bytes, needed); });
+}
+int rz_set_frame(rz_ctx* c, const rz_frame_params* p) {
+    return guarded(c, "rz_set_frame", [&] { return set_frame_impl(c, p); });
+}
+int rz_present(rz_ctx* c, const rz_present_params* pp, uint8_t* rgba8, size_t rgba8_bytes, float* rgb32f, size_t rgb32f_bytes) {
+    return guarded(c, "rz_present", [&] { return present_impl(c, pp, rgba8, rgba8_bytes, rgb32f, rgb32f_bytes); });
+}
+int rz_resolve_rgba8(rz_ctx* c, uint8_t* rgba8, size_t bytes) {
+    return guarded(c, "rz_resolve_rgba8", [&] { return resolve_rgba8_impl(c, rgba8, bytes); });
+}
+int rz_bind_accum(rz_ctx* c, void* device_rgba, size_t bytes) {
+    return guarded(c, "rz_bind_accum", [&] { return bind_accum_impl(c, device_rgba, bytes); });
+}
+int rz_read_accum(rz_ctx* c, float* rgba, size_t bytes) {
+    return guarded(c, "rz_read_accum", [&] { return read_accum_impl(c, rgba, bytes); });
+}
+int rz_clear_accum(rz_ctx* c) {
+    return guarded(c, "rz_clear_accum", [&] { return clear_accum_impl(c); });
+}
+
+int rz_debug_fail_alloc(rz_ctx* c, int nth) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    c->failAllocCountdown = nth > 0 ? nth : 0;
+    return RZ_OK;
 }
 
 }  // extern "C"

@@ -312,7 +312,9 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
             // equals the currentIor left by the previous one (any version will do if the sample never read it), and
             // stops at the first sample that lacks the version it needs; exactly the lanes that lack the wanted
             // version are then (re)run.  currentIor only ever takes the values 1.0 and the ior of a transparent
-            // material, so with one glass material every sample is computed at most twice.
+            // material, so with one glass material every sample is computed at most twice.  Keys are compared by BIT
+            // PATTERN: a NaN ior (the shader just propagates it) would never equal itself as a float and the loop below
+            // would re-run the same sample for ever.
             float4* verL = addL;                                  // [2][64]: addend FS:717, .w = incoming ior (key)
             float4* verS = addL + 128;                            // [2][64]: addend FS:709, .w = outgoing ior
             int* vinfo = reinterpret_cast<int*>(addL + 256);      // [2][64]: bit0 valid, bit1 usedIor
@@ -333,7 +335,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
                 const int sIdx = spp >= 64 ? lane : s;            // index of my sample within its pixel's batch
                 bool have = false;
 #pragma unroll
-                for (int v = 0; v < 2; ++v) have = have || ((infov[v] & 1) && (!(infov[v] & 2) || keyv[v] == want));
+                for (int v = 0; v < 2; ++v) have = have || ((infov[v] & 1) && (!(infov[v] & 2) || __float_as_uint(keyv[v]) == __float_as_uint(want)));
                 const bool run = mine && sIdx >= cons && !have;
                 Tally att = {};
                 if (run) {
@@ -390,7 +392,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
 #pragma unroll
                         for (int v = 0; v < 2; ++v) {
                             const int inf = vinfo[v * 64 + k];
-                            if (pick < 0 && (inf & 1) && (!(inf & 2) || verL[v * 64 + k].w == iorPix)) pick = v;
+                            if (pick < 0 && (inf & 1) && (!(inf & 2) || __float_as_uint(verL[v * 64 + k].w) == __float_as_uint(iorPix))) pick = v;
                         }
                         if (pick < 0) break;
                         const float4 L = verL[pick * 64 + k], S = verS[pick * 64 + k];

@@ -113,4 +113,73 @@ private:
     int width_ = 0, height_ = 0;
 };
 
+// The same frontend glue for N GPUs of one node driven by ONE process: every device holds the whole scene, renders the
+// 8x8-pixel tiles t with t % N == its rank, and one RCCL reduce per frame lands the image on rank 0 (rz_group_*).
+// A frontend written against Renderer switches by changing the type.
+class GroupRenderer {
+public:
+    explicit GroupRenderer(int ndev, const int* devices = nullptr, unsigned flags = RZ_FLAG_NONE)
+        : g_(rz_group_create(ndev, devices, flags)) {
+        if (!g_) throw std::runtime_error(std::string("rz_group_create: ") + rz_group_last_error(nullptr));
+    }
+    ~GroupRenderer() { rz_group_destroy(g_); }
+    GroupRenderer(const GroupRenderer&) = delete;
+    GroupRenderer& operator=(const GroupRenderer&) = delete;
+
+    int size() const { return rz_group_size(g_); }
+    void initializeSSBOs(const Scene& scene, bool shareMeshes = false) {
+        if (!buffers_.build(scene, shareMeshes)) throw std::runtime_error("scene build failed");
+        up(RZ_BIND_TRIANGLES, buffers_.allTriangles);
+        up(RZ_BIND_MATERIALS, scene.materials);
+        up(RZ_BIND_LIGHTS, scene.lights);
+        up(RZ_BIND_TLAS_NODES, buffers_.tlasNodes);
+        up(RZ_BIND_TLAS_INDICES, buffers_.tlasTriIndices);
+        up(RZ_BIND_BLAS_NODES, buffers_.allBLASNodes);
+        up(RZ_BIND_BLAS_INDICES, buffers_.allBLASTriIndices);
+        up(RZ_BIND_INSTANCES, buffers_.meshInstances);
+    }
+    void updateDynamicBVHAndSSBOs(const Scene& scene) {
+        buffers_.updateDynamic(scene);
+        upd(RZ_BIND_INSTANCES, buffers_.meshInstances);
+        upd(RZ_BIND_TLAS_NODES, buffers_.tlasNodes);
+        upd(RZ_BIND_TLAS_INDICES, buffers_.tlasTriIndices);
+    }
+    void sendSceneDataToShader(const Scene& scene, int width, int height, int bounceBudget, int spp = 1, int sampleBase = 0) {
+        rz_frame_params p{};
+        p.width = width; p.height = height;
+        mat4 iv = inverse(scene.camera.viewMatrix), ip = inverse(scene.camera.projectionMatrix);
+        std::memcpy(p.inv_view, iv.m, 64); std::memcpy(p.inv_proj, ip.m, 64);
+        std::memcpy(p.view, scene.camera.viewMatrix.m, 64); std::memcpy(p.proj, scene.camera.projectionMatrix.m, 64);
+        p.cam_pos[0] = scene.camera.position.x; p.cam_pos[1] = scene.camera.position.y; p.cam_pos[2] = scene.camera.position.z;
+        p.num_lights = (int)scene.lights.size();
+        p.bounce_budget = bounceBudget; p.spp = spp; p.sample_base = sampleBase;
+        p.tile_rank = 0; p.tile_nranks = 1;         // filled in per member by the group
+        check(rz_group_set_frame(g_, &p), "rz_group_set_frame");
+        width_ = width; height_ = height;
+    }
+    // glDrawArrays on every device, then the one collective, all asynchronous
+    void draw() { check(rz_group_render(g_), "rz_group_render"); check(rz_group_reduce(g_, 0), "rz_group_reduce"); }
+    void finish() { check(rz_group_sync(g_), "rz_group_sync"); }
+    std::vector<float> readFrame() {
+        std::vector<float> out((size_t)width_ * height_ * 4);
+        check(rz_group_read_frame(g_, out.data(), out.size() * sizeof(float)), "rz_group_read_frame");
+        return out;
+    }
+    rz_group* group() { return g_; }
+
+private:
+    template <class T> void up(rz_binding b, const std::vector<T>& v) {
+        check(rz_group_upload(g_, b, v.data(), v.size() * sizeof(T)), "rz_group_upload");
+    }
+    template <class T> void upd(rz_binding b, const std::vector<T>& v) {
+        check(rz_group_update(g_, b, 0, v.data(), v.size() * sizeof(T)), "rz_group_update");
+    }
+    void check(int rc, const char* what) {
+        if (rc != RZ_OK) throw std::runtime_error(std::string(what) + ": " + rz_group_last_error(g_));
+    }
+    rz_group* g_;
+    SceneBuffers buffers_;
+    int width_ = 0, height_ = 0;
+};
+
 }  // namespace rayzen

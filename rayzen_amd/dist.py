@@ -45,3 +45,132 @@ def reduce_accum(tensor, dst=0, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return tensor
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The multi-GPU group of the C-ABI (include/rayzen_hip.h: rz_group_*; rayzen_amd/csrc/hip/rz_group.hip): contexts +
+# RCCL communicator owned by librayzen_hip.so.  This class is only a ctypes view of it.
+# ---------------------------------------------------------------------------------------------------------
+
+def rccl_version():
+    """Version of the RCCL the library binds (no GPU needed)."""
+    import ctypes as C
+    from . import _lib
+    v = C.c_int(0)
+    L = _lib.hip()
+    rc = L.rz_group_rccl_version(C.byref(v))
+    if rc != 0:
+        raise RuntimeError(f"rz_group_rccl_version failed ({rc}): {L.rz_group_last_error(None).decode()}")
+    return v.value
+
+
+def unique_id():
+    """128-byte communicator id (ncclGetUniqueId): rank 0 makes it, every rank passes it to Group.create_rank."""
+    import ctypes as C
+    from . import _lib
+    buf = (C.c_char * 128)()
+    L = _lib.hip()
+    rc = L.rz_group_unique_id(buf)
+    if rc != 0:
+        raise RuntimeError(f"rz_group_unique_id failed ({rc}): {L.rz_group_last_error(None).decode()}")
+    return bytes(buf)
+
+
+class Group:
+    """N tile-sharded contexts and their RCCL communicator(s)."""
+
+    def __init__(self, handle):
+        from . import _lib
+        self._L = _lib.hip()
+        self._g = handle
+        self.width = self.height = 0
+
+    @classmethod
+    def create(cls, ndev, devices=None, flags=0):
+        """One process driving ndev devices (ncclCommInitAll)."""
+        import ctypes as C
+        from . import _lib
+        L = _lib.hip()
+        arr = (C.c_int * ndev)(*devices) if devices is not None else None
+        g = L.rz_group_create(int(ndev), arr, int(flags))
+        if not g:
+            raise RuntimeError("rz_group_create failed: " + L.rz_group_last_error(None).decode())
+        return cls(g)
+
+    @classmethod
+    def create_rank(cls, device, rank, nranks, uid, flags=0):
+        """One process per GPU (ncclCommInitRank); blocks until every rank has joined."""
+        import ctypes as C
+        from . import _lib
+        L = _lib.hip()
+        buf = (C.c_char * 128).from_buffer_copy(uid)
+        g = L.rz_group_create_rank(int(device), int(rank), int(nranks), buf, int(flags))
+        if not g:
+            raise RuntimeError("rz_group_create_rank failed: " + L.rz_group_last_error(None).decode())
+        return cls(g)
+
+    def close(self):
+        g, self._g = getattr(self, "_g", None), None
+        if g:
+            self._L.rz_group_destroy(g)
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc != 0:
+            from .renderer import RayZenError
+            raise RayZenError(what, rc, self._L.rz_group_last_error(self._g).decode())
+
+    @property
+    def size(self):
+        return self._L.rz_group_size(self._g)
+
+    @property
+    def local_count(self):
+        return self._L.rz_group_local_count(self._g)
+
+    def rank(self, local=0):
+        return self._L.rz_group_rank(self._g, local)
+
+    def upload_scene(self, scene):
+        from .scene import BINDING_DTYPES
+        for b in BINDING_DTYPES:
+            a = np.ascontiguousarray(scene.arrays[b])
+            self._check(self._L.rz_group_upload(self._g, int(b), a.ctypes.data if a.nbytes else None, a.nbytes), "rz_group_upload")
+
+    def update(self, binding, array, offset_bytes=0):
+        a = np.ascontiguousarray(array)
+        self._check(self._L.rz_group_update(self._g, int(binding), int(offset_bytes), a.ctypes.data if a.nbytes else None, a.nbytes),
+                    "rz_group_update")
+
+    def set_frame(self, params):
+        import ctypes as C
+        self._check(self._L.rz_group_set_frame(self._g, C.byref(params)), "rz_group_set_frame")
+        self.width, self.height = params.width, params.height
+
+    def render(self):
+        self._check(self._L.rz_group_render(self._g), "rz_group_render")
+
+    def reduce(self, root=0):
+        self._check(self._L.rz_group_reduce(self._g, int(root)), "rz_group_reduce")
+
+    def sync(self):
+        self._check(self._L.rz_group_sync(self._g), "rz_group_sync")
+
+    def read_frame(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._L.rz_group_read_frame(self._g, out.ctypes.data, out.nbytes), "rz_group_read_frame")
+        return out
+
+    def frame_device_ptr(self):
+        return self._L.rz_group_frame_device_ptr(self._g)
+
+    def member(self, local=0):
+        """A Renderer view of one member's context (per-device calls: counters, timings); does not own it."""
+        from .renderer import Renderer
+        r = Renderer.__new__(Renderer)
+        r._L = self._L
+        r._c = self._L.rz_group_ctx(self._g, int(local))
+        r.width, r.height = self.width, self.height
+        r.close = lambda: None          # the group owns the context
+        return r

@@ -165,6 +165,10 @@ class Renderer:
     def last_kernel_name(self):
         return self._L.rz_last_kernel_name(self._c).decode()
 
+    def debug_fail_alloc(self, nth):
+        """Test hook: the nth host allocation site reached from now on throws std::bad_alloc inside the library."""
+        self._check(self._L.rz_debug_fail_alloc(self._c, int(nth)), "rz_debug_fail_alloc")
+
     def accum_device_ptr(self):
         return self._L.rz_accum_device_ptr(self._c)
 

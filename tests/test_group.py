@@ -1,0 +1,95 @@
+"""The multi-GPU group of the C-ABI (rz_group_*, include/rayzen_hip.h).  CPU part: RCCL is bound at run time and every
+entry point the group needs resolves; arguments are validated before any device is touched.  GPU part (one GPU on the
+box): a 1-rank group goes through the real ncclCommInitRank / ncclCommInitAll + ncclReduce and must hand back the
+single-context frame bit for bit."""
+import numpy as np
+import pytest
+
+from rayzen_amd import dist as D
+from rayzen_amd import _lib
+
+
+def test_rccl_binds_at_run_time_without_a_gpu():
+    v = D.rccl_version()
+    assert v >= 21800, v            # RCCL of ROCm 7.x reports an NCCL 2.2x version number
+
+
+def test_library_has_no_link_time_dependency_on_rccl():
+    import subprocess
+    out = subprocess.run(["readelf", "-d", _lib.HIP_SO], capture_output=True, text=True).stdout
+    needed = [l for l in out.splitlines() if "NEEDED" in l]
+    assert needed and not any("rccl" in l for l in needed), needed
+
+
+def test_group_arguments_are_validated_before_any_device_is_touched():
+    L = _lib.hip()
+    assert not L.rz_group_create(0, None, 0)
+    assert b"ndev" in L.rz_group_last_error(None)
+    uid = bytes(128)
+    import ctypes as C
+    buf = (C.c_char * 128).from_buffer_copy(uid)
+    assert not L.rz_group_create_rank(0, 3, 2, buf, 0)
+    assert b"rank 3 of 2" in L.rz_group_last_error(None)
+    assert not L.rz_group_create_rank(0, 0, 1, None, 0)
+    assert L.rz_group_size(None) == 0 and L.rz_group_local_count(None) == 0 and L.rz_group_rank(None, 0) == -1
+    assert L.rz_group_render(None) == -1 and L.rz_group_reduce(None, 0) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["rank", "all"])
+def test_one_rank_group_renders_reduces_and_matches_the_oracle(how):
+    from rayzen_amd import scene as S
+    from rayzen_amd.renderer import frame_params
+    from helpers import hip_render, oracle_render
+    sc = S.bunny_scene(n=8, extras=True)
+    W, H, spp, b = 96, 54, 3, 4
+    g = D.Group.create_rank(0, 0, 1, D.unique_id()) if how == "rank" else D.Group.create(1)
+    assert g.size == 1 and g.local_count == 1 and g.rank(0) == 0
+    g.upload_scene(sc)
+    g.set_frame(frame_params(sc.camera, W, H, len(sc.lights), b, spp))
+    for _ in range(2):                  # the reduce is out of place: a second frame is not polluted by the first
+        g.render()
+        g.reduce(0)
+    got = g.read_frame()
+    g.close()
+    ref = oracle_render(sc, W, H, spp, b)
+    assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+    assert (got.view(np.uint32) == hip_render(sc, W, H, spp, b).view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+def test_group_frame_continues_with_sample_base():
+    """Chunked accumulation through the group: members' accumulation buffers are never overwritten by the reduce."""
+    from rayzen_amd import scene as S
+    from rayzen_amd.renderer import frame_params
+    from helpers import oracle_render
+    sc = S.bunny_scene(n=8, extras=True)
+    W, H, b = 64, 40, 4
+    g = D.Group.create(1)
+    g.upload_scene(sc)
+    for base, k in ((0, 2), (2, 3)):
+        g.set_frame(frame_params(sc.camera, W, H, len(sc.lights), b, k, base))
+        g.render()
+        g.reduce(0)
+    got = g.read_frame()
+    g.close()
+    ref = oracle_render(sc, W, H, 5, b)
+    assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+def test_cpp_group_example_is_bit_identical_to_a_single_context(tmp_path):
+    """examples/render_group.cpp: C++ frontend -> GroupRenderer (Renderer.h) -> rz_group_* -> RCCL; the program itself
+    compares the reduced frame with a single-context render and exits 0 only if they are the same bytes."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "render_group")
+    lib = os.path.join(root, "rayzen_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(root, "include"), "-I",
+                           os.path.join(root, "rayzen_amd", "csrc", "host"),
+                           os.path.join(root, "examples", "render_group.cpp"), "-L", lib, "-lrayzen_host",
+                           "-lrayzen_hip", f"-Wl,-rpath,{lib}", "-o", exe])
+    out = subprocess.run([exe, "0", "160", "96", "3"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "bit-identical" in out.stdout
