@@ -13,6 +13,6 @@ else
   for f in $(git -C "$ROOT" ls-tree --name-only "$REV" include/); do git -C "$ROOT" show "$REV:$f" > "$T/include/$(basename $f)"; done
   H=$T/hip; INC=$T/include
 fi
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math "$@" -I "$INC" -I "$H" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize "$@" -I "$INC" -I "$H" \
     -shared -o "$ROOT/rayzen_amd/lib/librayzen_hip_$NAME.so" "$H"/*.hip 2>/dev/null
 echo "built librayzen_hip_$NAME.so from $REV $*"

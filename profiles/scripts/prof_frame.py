@@ -1,0 +1,26 @@
+"""One counted C2 frame with the RZ_PROF diagnostic build (RAYZEN_HIP_SO=rayzen_amd/lib/librayzen_hip_prof.so):
+prints per-site wave executions / active lanes and the wave-cycle split to stderr."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from rayzen_amd import scene as S
+from rayzen_amd.renderer import Renderer, frame_params
+
+W, H, SPP, B = 1920, 1080, 64, 4
+which = sys.argv[1] if len(sys.argv) > 1 else "c2"
+if which == "c2":
+    sc = S.bunny_scene(n=76, aspect=W / H)
+elif which == "c4":
+    sc, SPP = S.instanced_scene(n=76, count=16, aspect=W / H), 16
+elif which == "c5":
+    W, H, SPP, B = 3840, 2160, 16, 8
+    sc = S.stress_scene(n=289, aspect=W / H)
+r = Renderer(0)
+r.upload_scene(sc)
+r.set_frame(frame_params(sc.camera, W, H, len(sc.lights), B, SPP))
+r.render()
+r.sync()
+c = r.render_counted()
+print(which, r.render_history_ms(), c)
+r.close()

@@ -103,27 +103,43 @@ __device__ __forceinline__ RayPk make_raypk(v3 o, v3 inv) {
 }
 // (written as 2-vector IR, not inline asm: the compiler folds the broadcast into op_sel itself, and it then knows the
 // products are canonical, so the min/max that follow need no v_max(x, x) quieting first)
-#define RZ_PLANES(out, C, box, o2, i2, SEL)                                                                          \
+#define RZ_PLANES(out, box, o2, i2, SEL)                                                                             \
     do {                                                                                                             \
         const f32x2 ob_ = __builtin_shufflevector(o2, o2, SEL, SEL), ib_ = __builtin_shufflevector(i2, i2, SEL, SEL);\
         out = ((box) - ob_) * ib_;                                                                                   \
     } while (0)
+// OCT < 0: the shader's per-axis min / max (FS:384-385).  OCT in 0..7: the wave's rays all point into octant OCT
+// (bit k set: direction component k negative) and every reciprocal is finite and nonzero; then for each axis
+// (plane_min - o) * inv <= (plane_max - o) * inv when inv > 0 and >= when inv < 0 -- subtraction, multiplication and
+// their roundings are monotone -- so min / max of the two products ARE one and the other product: the six v_min / v_max
+// per box are compile-time register choices.  (With a zero direction component the products can be 0 * inf = NaN,
+// which minNum / maxNum skip: those rays keep the generic form.)  v_min_f32 / v_max_f32 issue at about 3.4 cycles per
+// wave on gfx950 against 2 for v_mul / v_add (profiles/r02_valu_issue): 12 of them per pair of boxes were a quarter of
+// a descend step's vector-ALU time.
+template <int OCT>
 __device__ __forceinline__ bool slab_finish(f32x2 tx, f32x2 ty, f32x2 tz, float& tmin) {
-    const float sx = fmin_(tx.x, tx.y), sy = fmin_(ty.x, ty.y), sz = fmin_(tz.x, tz.y);
-    const float gx = fmax_(tx.x, tx.y), gy = fmax_(ty.x, ty.y), gz = fmax_(tz.x, tz.y);
+    float sx, sy, sz, gx, gy, gz;
+    if constexpr (OCT < 0) {
+        sx = fmin_(tx.x, tx.y); sy = fmin_(ty.x, ty.y); sz = fmin_(tz.x, tz.y);
+        gx = fmax_(tx.x, tx.y); gy = fmax_(ty.x, ty.y); gz = fmax_(tz.x, tz.y);
+    } else {
+        sx = (OCT & 1) ? tx.y : tx.x; gx = (OCT & 1) ? tx.x : tx.y;
+        sy = (OCT & 2) ? ty.y : ty.x; gy = (OCT & 2) ? ty.x : ty.y;
+        sz = (OCT & 4) ? tz.y : tz.x; gz = (OCT & 4) ? tz.x : tz.y;
+    }
     tmin = fmax_(fmax_(sx, sy), sz);
     const float tmax = fmin_(fmin_(gx, gy), gz);
     return tmax >= fmax_(tmin, 0.0f);
 }
-#define RZ_SLAB_PAIR(C, R, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr)                                                   \
+#define RZ_SLAB_PAIR(OCT, R, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr)                                                  \
     do {                                                                                                             \
         f32x2 ax_, ay_, az_, bx_, by_, bz_;                                                                          \
-        RZ_PLANES(ax_, C, lx, (R).oxy, (R).ixy, 0); RZ_PLANES(ay_, C, ly, (R).oxy, (R).ixy, 1);                      \
-        RZ_PLANES(az_, C, lz, (R).ozz, (R).izz, 0);                                                                  \
-        RZ_PLANES(bx_, C, rx, (R).oxy, (R).ixy, 0); RZ_PLANES(by_, C, ry, (R).oxy, (R).ixy, 1);                      \
-        RZ_PLANES(bz_, C, rz, (R).ozz, (R).izz, 0);                                                                  \
-        hl = slab_finish(ax_, ay_, az_, tl);                                                                         \
-        hr = slab_finish(bx_, by_, bz_, tr);                                                                         \
+        RZ_PLANES(ax_, lx, (R).oxy, (R).ixy, 0); RZ_PLANES(ay_, ly, (R).oxy, (R).ixy, 1);                      \
+        RZ_PLANES(az_, lz, (R).ozz, (R).izz, 0);                                                                  \
+        RZ_PLANES(bx_, rx, (R).oxy, (R).ixy, 0); RZ_PLANES(by_, ry, (R).oxy, (R).ixy, 1);                      \
+        RZ_PLANES(bz_, rz, (R).ozz, (R).izz, 0);                                                                  \
+        hl = slab_finish<OCT>(ax_, ay_, az_, tl);                                                                    \
+        hr = slab_finish<OCT>(bx_, by_, bz_, tr);                                                                         \
     } while (0)
 
 // FS:391-416 without the outputs that are pure functions of (ray, t, triangle).
@@ -209,71 +225,87 @@ __device__ __forceinline__ bool pop_entry(const BlasStackT<OVF>& S, int& sp, flo
 // One instance's BLAS (FS:419-454) in the instance's local space.
 // bstk: this lane's stack (LDS window + optional overflow).
 // Returns the winning triangle (absolute DevTri index) or -1; tLoc = its t.
-template <bool COUNT, bool OVF>
-__device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance* __restrict__ I, v3 lo, v3 ld,
-                                             float& tLocOut, const BlasStackT<OVF>& bstk, Tally& c) {
+// OCT: -1 generic, 0..7 the wave's common direction octant (slab_finish).
+template <bool COUNT, bool OVF, int OCT>
+__device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, const DevTri* __restrict__ tris, v3 lo, v3 ld, v3 inv,
+                                         bool go, int cur, float& tLocOut, const BlasStackT<OVF>& bstk, Tally& c) {
     float tLoc = 1e30f;
     int best = -1;
-    const v3 inv = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
-    if (COUNT) c.blas_nodes += 1;            // the shader pops the root
-    float tminRoot;
-    bool go = slab(lo, inv, I->rootMin[0], I->rootMin[1], I->rootMin[2], I->rootMax[0], I->rootMax[1], I->rootMax[2],
-                   tminRoot);
-    go = go && !(tminRoot > tLoc) && !(I->flags & 1);
-    int cur = I->rootEnc;
     int sp = 0;
-    const DevPair* __restrict__ pairs = K.pairs + I->pairBase;
-    const DevTri* __restrict__ tris = K.tris + I->triBase;
     const RayPk RP = make_raypk(lo, inv);
-    // "while-while": the inner loop walks internal nodes; a lane that reaches a leaf parks there (its own
-    // sequence of operations is unchanged) until the lanes of the wave still descending are few, then the
-    // parked lanes test their leaves together.  Without this the wave ran the triangle tests for ~7 of its
-    // 64 lanes at a time.
-    while (go) {
-        while (go && cur >= 0) {
-            RZ_SITE(c, 3);
-            const DevPair* pp = pairs + cur;
-            if (COUNT) c.blas_nodes += 2;        // the shader pushes, and later pops, both children
-            float tl, tr;
-            bool hl, hr;
-            int lenc, renc;
+    // Lane state: `cur` -- >= 0 an internal node (its DevPair), < 0 a leaf (~cur = first << 4 | count; -1 is the empty
+    // leaf that a culled stack entry turns into) -- and the stack height `sp`.  A lane is finished when cur == -1 and
+    // sp == 0 (an empty leaf with nothing left to pop): no separate flag.
+    // The loops below are WAVE-UNIFORM loops with predicated bodies (their trip conditions are ballots, forced into
+    // scalar registers), not per-lane `while (go && cur >= 0)` loops: for those hipcc keeps a mask of the lanes that
+    // have left each loop level and spent more scalar instructions on exec-mask bookkeeping (~55 per descend step) than
+    // vector instructions on the two box tests (~50) -- and the kernel is bound by instruction issue, scalar
+    // instructions included.
+    if (!go) cur = -1;
+    // (the bound is a backstop, never reached: a BLAS of n nodes is walked in fewer than 2n rounds and the host has
+    //  checked that the node array is a tree -- but a wave that can spin for ever takes the whole device with it)
+    for (unsigned round = 0; round < (1u << 24); ++round) {
+        // "while-while": walk internal nodes; a lane that reaches a leaf parks there (its own sequence of operations is
+        // unchanged) until the lanes of the wave still descending are few, then the parked lanes test their leaves
+        // together.  Without this the wave ran the triangle tests for ~7 of its 64 lanes at a time.
+        // (the lane-count test sits at the END of the body: lanes at internal nodes always advance at least one step per
+        //  round of the outer loop, or one to three stragglers with nobody at a leaf would never move again)
+        for (;;) {
+            const bool act = cur >= 0;
+            if (__ballot(act) == 0ull) break;
+            if (act) {
+                RZ_SITE(c, 3);
+                const DevPair* pp = pairs + cur;
+                if (COUNT) c.blas_nodes += 2;        // the shader pushes, and later pops, both children
+                float tl, tr;
+                bool hl, hr;
+                int lenc, renc;
 #if RZ_SCALAR_UNIFORM
-            const DevPair* upp = reinterpret_cast<const DevPair*>(
-                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)pp >> 32)) << 32) |
-                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)pp));
-            // (the builtin returns a signed int: without the (unsigned) a low half with bit 31 set sign-extended over
-            //  the high half, the comparison below then failed for every lane and the scalar path was never taken --
-            //  half of all buffer placements ran 5.7 % slower, found from a 2x TCP access count in the slow runs)
-            if (__ballot(pp != upp) == 0ull) {       // every active lane wants the same pair: one scalar fetch,
-                RZ_SITE(c, 7);                        // box values consumed straight from SGPRs
-                const f32x16 q = sload16(upp);
-                const f32x2 lx = {q[0], q[1]}, ly = {q[2], q[3]}, lz = {q[4], q[5]};
-                const f32x2 rx = {q[6], q[7]}, ry = {q[8], q[9]}, rz = {q[10], q[11]};
-                RZ_SLAB_PAIR("s", RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
-                lenc = __float_as_int(q[12]);
-                renc = __float_as_int(q[13]);
-            } else
+                const DevPair* upp = reinterpret_cast<const DevPair*>(
+                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)pp >> 32)) << 32) |
+                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)pp));
+                // (the builtin returns a signed int: without the (unsigned) a low half with bit 31 set sign-extended over
+                //  the high half, the comparison below then failed for every lane and the scalar path was never taken --
+                //  half of all buffer placements ran 5.7 % slower, found from a 2x TCP access count in the slow runs)
+                if (__ballot(pp != upp) == 0ull) {       // every active lane wants the same pair: one scalar fetch,
+                    RZ_SITE(c, 7);                        // box values consumed straight from SGPRs
+                    const f32x16 q = sload16(upp);
+                    const f32x2 lx = {q[0], q[1]}, ly = {q[2], q[3]}, lz = {q[4], q[5]};
+                    const f32x2 rx = {q[6], q[7]}, ry = {q[8], q[9]}, rz = {q[10], q[11]};
+                    RZ_SLAB_PAIR(OCT, RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
+                    lenc = __float_as_int(q[12]);
+                    renc = __float_as_int(q[13]);
+                } else
 #endif
-            {
-                const float4* __restrict__ p4 = reinterpret_cast<const float4*>(pp);
-                float4 p0 = p4[0], p1 = p4[1], p2 = p4[2], p3 = p4[3];
+                {
+                    const float4* __restrict__ p4 = reinterpret_cast<const float4*>(pp);
+                    float4 p0 = p4[0], p1 = p4[1], p2 = p4[2], p3 = p4[3];
 #ifndef RZ_EXP_NOKEEP
-                RZ_KEEP4(p0); RZ_KEEP4(p3);
+                    RZ_KEEP4(p0); RZ_KEEP4(p3);
 #endif
-                const f32x2 lx = {p0.x, p0.y}, ly = {p0.z, p0.w}, lz = {p1.x, p1.y};
-                const f32x2 rx = {p1.z, p1.w}, ry = {p2.x, p2.y}, rz = {p2.z, p2.w};
-                RZ_SLAB_PAIR("v", RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
-                lenc = __float_as_int(p3.x);
-                renc = __float_as_int(p3.y);
+                    const f32x2 lx = {p0.x, p0.y}, ly = {p0.z, p0.w}, lz = {p1.x, p1.y};
+                    const f32x2 rx = {p1.z, p1.w}, ry = {p2.x, p2.y}, rz = {p2.z, p2.w};
+                    RZ_SLAB_PAIR(OCT, RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
+                    lenc = __float_as_int(p3.x);
+                    renc = __float_as_int(p3.y);
+                }
+                // The shader pushes left, then right, and pops right at once (FS:449-450, 428-430).
+                //  * right hit and not culled: continue into it; a hit left child waits on the stack with its entry distance;
+                //  * else the next pop IS the left child just pushed: enter it directly (same cull against the same tLoc)
+                //    -- no LDS round trip;
+                //  * neither box hit: pop an older entry.
+                const bool takeR = hr && !(tr > tLoc);
+                if (hl && takeR) push_entry(bstk, sp, make_uint2((unsigned)lenc, __float_as_uint(tl)));
+                int next = takeR ? renc : ((tl > tLoc) ? -1 : lenc);
+                if (!hl && !takeR) {
+                    if (!pop_entry(bstk, sp, tLoc, next)) next = -1;
+                }
+                cur = next;
             }
-            if (hl) {
-                push_entry(bstk, sp, make_uint2((unsigned)lenc, __float_as_uint(tl)));
-            }
-            if (hr && !(tr > tLoc)) cur = renc;
-            else go = pop_entry(bstk, sp, tLoc, cur);
-            if (__popcll(__ballot(go && cur >= 0)) < RZ_DESCEND_MIN_LANES) break;
+            if (__popcll(__ballot(cur >= 0)) < RZ_DESCEND_MIN_LANES) break;
         }
-        if (go && cur < 0) {
+        if (__ballot((cur != -1) || (sp > 0)) == 0ull) break;
+        if (cur < 0) {
             RZ_SITE(c, 1);
             // leaf: <= 4 triangles, contiguous in leaf order, tested in order (count 0: a culled stack entry)
             const int v = ~cur;
@@ -289,11 +321,59 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
                     if (t < tLoc) { tLoc = t; best = first + i; }
                 }
             }
-            go = pop_entry(bstk, sp, tLoc, cur);
+            if (!pop_entry(bstk, sp, tLoc, cur)) cur = -1;
         }
         RZ_SITE(c, 0);
     }
     tLocOut = tLoc;
+    return best;
+}
+
+#ifndef RZ_OCTANT_SLAB
+#define RZ_OCTANT_SLAB 1
+#endif
+template <bool COUNT, bool OVF>
+__device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance* __restrict__ I, v3 lo, v3 ld,
+                                             float& tLocOut, const BlasStackT<OVF>& bstk, Tally& c) {
+    const v3 inv = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+    if (COUNT) c.blas_nodes += 1;            // the shader pops the root
+    float tminRoot;
+    bool go = slab(lo, inv, I->rootMin[0], I->rootMin[1], I->rootMin[2], I->rootMax[0], I->rootMax[1], I->rootMax[2],
+                   tminRoot);
+    go = go && !(tminRoot > 1e30f) && !(I->flags & 1);
+    const int cur = I->rootEnc;
+    const DevPair* __restrict__ pairs = K.pairs + I->pairBase;
+    const DevTri* __restrict__ tris = K.tris + I->triBase;
+    int best;
+#if RZ_OCTANT_SLAB
+    if constexpr (!COUNT) {
+        // the lanes that will walk this BLAS: do they share a direction octant, with every reciprocal finite and nonzero?
+        const float big = __builtin_huge_valf();
+        const bool fin = (__builtin_fabsf(inv.x) < big) && (__builtin_fabsf(inv.y) < big) && (__builtin_fabsf(inv.z) < big) &&
+                         inv.x != 0.0f && inv.y != 0.0f && inv.z != 0.0f;
+        const int oct = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
+        const unsigned long long walkers = __ballot(go);
+        int uoct = -1;
+        if (walkers != 0ull) {
+            const int first = __builtin_amdgcn_readlane(oct, (int)__builtin_ctzll(walkers));
+            if (__ballot(go && (!fin || oct != first)) == 0ull) uoct = first;
+        }
+        switch (uoct) {
+            case 0: best = blas_walk<COUNT, OVF, 0>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
+            case 1: best = blas_walk<COUNT, OVF, 1>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
+            case 2: best = blas_walk<COUNT, OVF, 2>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
+            case 3: best = blas_walk<COUNT, OVF, 3>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
+            case 4: best = blas_walk<COUNT, OVF, 4>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
+            case 5: best = blas_walk<COUNT, OVF, 5>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
+            case 6: best = blas_walk<COUNT, OVF, 6>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
+            case 7: best = blas_walk<COUNT, OVF, 7>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
+            default: best = blas_walk<COUNT, OVF, -1>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
+        }
+    } else
+#endif
+    {
+        best = blas_walk<COUNT, OVF, -1>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c);
+    }
     return best < 0 ? -1 : best + I->triBase;
 }
 

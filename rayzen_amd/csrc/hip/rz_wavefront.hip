@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void wf_trace(const KParams K, const WFParams 
                 const RayPk RP = make_raypk(lo, linv);
                 const f32x2 lx = {p0.x, p0.y}, ly = {p0.z, p0.w}, lz = {p1.x, p1.y};
                 const f32x2 rx = {p1.z, p1.w}, ry = {p2.x, p2.y}, rz = {p2.z, p2.w};
-                RZ_SLAB_PAIR("v", RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
+                RZ_SLAB_PAIR(-1, RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
                 if (hl) {
                     bstk[sp * 64] = make_uint2((unsigned)__float_as_int(p3.x), __float_as_uint(tl));
                     ++sp;
