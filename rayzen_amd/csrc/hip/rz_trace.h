@@ -31,6 +31,9 @@
 
 namespace rz {
 
+#ifndef RZ_TLAS_MIN_LANES
+#define RZ_TLAS_MIN_LANES 1     // leave the TLAS pop loop when fewer lanes than this are still popping (the rest hold a leaf or are done): C4 (17 instances, 4 pixels per wave) 12.24 ms entering at once, 11.82 / 11.15 / 10.83 ms at 32 / 8 / 1; C2 indifferent
+#endif
 #ifndef RZ_DESCEND_MIN_LANES
 #define RZ_DESCEND_MIN_LANES 4   // leave the descend loop when fewer lanes than this still have an internal node (lane=sample kernel on C2: 1 -> 17.6 ms, 2 -> 17.4, 3..6 -> 17.15-17.2, 8 -> 17.3, 12 -> 17.4)
 #endif
@@ -388,19 +391,40 @@ __device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitR
     const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     int sp = 0;
     if (K.nTlasNodes > 0) { tstk[0] = 0; sp = 1; }
-    while (sp > 0) {
-        RZ_SITE(c, 4);
-        --sp;
-        const int nidx = tstk[sp * 64];
-        const float4* __restrict__ np = reinterpret_cast<const float4*>(K.tlasNodes + nidx);
-        const float4 n0 = np[0], n1 = np[1];
-        if (COUNT) c.tlas_nodes += 1;
-        float tmin;
-        if (!slab(o, inv, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, tmin) || tmin > tHit) continue;
-        const int leftFirst = __float_as_int(n0.w), count = __float_as_int(n1.w);
-        if (count > 0) {
-            for (int i = 0; i < count; ++i) {
-                const int instIdx = K.tlasIndices[leftFirst + i];
+    // The TLAS loop of FS:464-501, batched like the BLAS walk: a lane whose popped node is a leaf that passed the box
+    // test PARKS it (leafCount > 0) while the other lanes keep popping, and the parked lanes then enter their
+    // instances' BLAS together.  Entering at once -- as the shader's loop does -- ran the BLAS walks of a 16-instance
+    // scene 20 lanes wide: the lanes of a wave reach their leaves in different iterations.  Every lane still pops its
+    // own stack in its own order and updates its own tHit in the shader's order: same visits, same result.
+    // Both loops are wave-uniform (ballot conditions) with predicated bodies, see blas_walk.
+    int leafFirst = 0, leafCount = 0;
+    for (unsigned round = 0; round < (1u << 24); ++round) {
+        for (;;) {
+            const bool walk = leafCount == 0 && sp > 0;
+            if (__ballot(walk) == 0ull) break;
+            if (walk) {
+                RZ_SITE(c, 4);
+                --sp;
+                const int nidx = tstk[sp * 64];
+                const float4* __restrict__ np = reinterpret_cast<const float4*>(K.tlasNodes + nidx);
+                const float4 n0 = np[0], n1 = np[1];
+                if (COUNT) c.tlas_nodes += 1;
+                float tmin;
+                if (slab(o, inv, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, tmin) && !(tmin > tHit)) {
+                    const int lf = __float_as_int(n0.w), count = __float_as_int(n1.w);
+                    if (count > 0) { leafFirst = lf; leafCount = count; }
+                    else if (count < 0 && sp + 2 <= K.tlasStackCap) {   // count == 0: the host builder's empty root
+                        tstk[sp * 64] = lf; ++sp;
+                        tstk[sp * 64] = lf + 1; ++sp;
+                    }
+                }
+            }
+            if (__popcll(__ballot(leafCount == 0 && sp > 0)) < RZ_TLAS_MIN_LANES) break;
+        }
+        if (__ballot(leafCount > 0 || sp > 0) == 0ull) break;
+        if (leafCount > 0) {
+            for (int i = 0; i < leafCount; ++i) {
+                const int instIdx = K.tlasIndices[leafFirst + i];
                 const DevInstance* __restrict__ I = K.instances + instIdx;
                 if (COUNT) { c.tlas_leaf_indices += 1; c.instances += 1; }
                 RZ_SITE(c, 5);
@@ -415,9 +439,7 @@ __device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitR
                     if (tWorld < tHit) { tHit = tWorld; bestP = worldHit; bestTri = tri; bestInst = instIdx; }
                 }
             }
-        } else if (count < 0 && sp + 2 <= K.tlasStackCap) {   // count == 0: the host builder's empty root
-            tstk[sp * 64] = leftFirst; ++sp;
-            tstk[sp * 64] = leftFirst + 1; ++sp;
+            leafCount = 0;
         }
     }
     if (bestTri < 0) return false;
