@@ -154,20 +154,24 @@ __device__ __forceinline__ bool moller_trumbore(v3 o, v3 d, v3 v0, v3 e1, v3 e2,
     float f = 1.0f / a;
     v3 s = o - v0;
     float u = f * dot(s, h);
-    bool ok = !(__builtin_fabsf(a) < 0.0001f);
-    ok = ok && !(u < 0.0f || u > 1.0f);
+    // (every comparison is evaluated for every lane and the results are combined as lane masks: written as
+    //  `ok = ok && ...` hipcc wrapped each further pair of compares in its own exec-mask region, four scalar
+    //  instructions to spare some lanes two vector ones)
+    const bool aSmall = __builtin_fabsf(a) < 0.0001f;
+    const bool uLow = u < 0.0f, uHigh = u > 1.0f;
+    const bool ok1 = !aSmall && !uLow && !uHigh;
 #ifndef RZ_NO_TRI_EARLY_OUT
     // Wave-level early out after the shader's second test: the lanes of a wave are mostly samples of one pixel testing
     // the same triangle with near-identical rays, so they tend to fail together -- and then the second cross product,
     // two dot products and the remaining comparisons (about 30 of the test's 75 instructions) are skipped.  A lane's
     // own result is unchanged: values computed past a failed test were never used.
-    if (__ballot(ok) == 0ull) return false;
+    if (__ballot(ok1) == 0ull) return false;
 #endif
     v3 q = cross(s, e1);
     float v = f * dot(d, q);
     t = f * dot(e2, q);
-    ok = ok && !(v < 0.0f || u + v > 1.0f);
-    return ok && (t > 0.0001f);
+    const bool vLow = v < 0.0f, uvHigh = u + v > 1.0f, tOk = t > 0.0001f;
+    return ok1 && !vLow && !uvHigh && tOk;
 }
 
 // 3x4 packed column-major transforms of DevInstance
@@ -308,23 +312,30 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
             if (__popcll(__ballot(cur >= 0)) < RZ_DESCEND_MIN_LANES) break;
         }
         if (__ballot((cur != -1) || (sp > 0)) == 0ull) break;
-        if (cur < 0) {
-            RZ_SITE(c, 1);
-            // leaf: <= 4 triangles, contiguous in leaf order, tested in order (count 0: a culled stack entry)
+        {
+            // leaves: <= 4 triangles each, contiguous in leaf order, tested in order (count 0: a culled stack entry, or a
+            // finished lane); a wave-uniform loop over the triangle slot, lanes with fewer triangles sit out
+            const bool leaf = cur < 0;
             const int v = ~cur;
-            const int first = v >> 4, count = v & 15;
+            const int first = v >> 4, count = leaf ? (v & 15) : 0;
             if (COUNT) c.triangles += (unsigned)count;
-            for (int i = 0; i < count; ++i) {
-                RZ_SITE(c, 2);
-                const float4* __restrict__ tp = reinterpret_cast<const float4*>(tris + first + i);
-                float4 a = tp[0], b = tp[1], cc = tp[2];
-                RZ_KEEP4(a);
-                float t;
-                if (moller_trumbore(lo, ld, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, cc.x), t)) {
-                    if (t < tLoc) { tLoc = t; best = first + i; }
+            if (leaf) RZ_SITE(c, 1);
+            for (int i = 0;; ++i) {
+                const bool test = i < count;
+                if (__ballot(test) == 0ull) break;
+                if (test) {
+                    RZ_SITE(c, 2);
+                    const float4* __restrict__ tp = reinterpret_cast<const float4*>(tris + first + i);
+                    float4 a = tp[0], b = tp[1], cc = tp[2];
+                    RZ_KEEP4(a);
+                    float t;
+                    const bool hit = moller_trumbore(lo, ld, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, cc.x), t);
+                    if (hit && t < tLoc) { tLoc = t; best = first + i; }
                 }
             }
-            if (!pop_entry(bstk, sp, tLoc, cur)) cur = -1;
+            if (leaf) {
+                if (!pop_entry(bstk, sp, tLoc, cur)) cur = -1;
+            }
         }
         RZ_SITE(c, 0);
     }
