@@ -4,19 +4,20 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one frame of synthetic input: BASELINE.json configs[1],
-the ~69k-triangle "bunny" scene (procedural stand-in, see rayzen_amd/scene.py) at 1920x1080,
-4 bounces, 64 samples per pixel per GPU.  At N > 1 the frame's 8x8-pixel tiles are dealt round-robin
-to the ranks, every rank renders 64*N spp of its own pixels (per-GPU work is constant: weak scaling),
-and one RCCL reduce(SUM) per step lands the frame on rank 0 (rayzen_amd/dist.py).  Scene buffers are
-resident in HBM before the timed region; nothing is skipped inside it.
+One "step" = one pass of the hot path over one frame of synthetic input: BASELINE.json configs[1], the
+~69k-triangle "bunny" scene (procedural stand-in, see rayzen_amd/scene.py) at 1920x1080, 4 bounces, 64 samples per
+pixel per GPU.  At N > 1 the frame's 8x8-pixel tiles are dealt round-robin to the ranks and ONE RCCL reduce(SUM) per
+step lands the frame on rank 0 -- both through the C-ABI's multi-GPU group (include/rayzen_hip.h: rz_group_*; one
+process per GPU, ncclCommInitRank with an id broadcast over torch.distributed, the reduce enqueued on the render
+stream).  Default N > 1 workload: every rank renders 64*N spp of its own pixels (per-GPU work constant: "weak");
+`--spp-total T` fixes the frame at T spp instead ("strong"; `--spp-total 256` at N = 8 is BASELINE configs[2]).
+Scene buffers are resident in HBM before the timed region; nothing is skipped inside it.
 
-Rank 0 prints ONE JSON line.  `value` = total camera paths (pixels x spp) of all ranks / wall time of
-the K timed steps (max over ranks).  `roofline` prices the render kernel: `achieved` = algorithmic
-bytes per launch (the bytes RayZen's shader would read from its SSBOs for exactly this frame, counted
-by an untimed instrumented launch) / the kernel's mean duration measured with HIP
-events on its stream.  `cpu_baseline` = the oracle (a CPU port of the same path) timed on a bounded
-sample of the same frame, which doubles as a full-size parity check of those pixels.
+Rank 0 prints ONE JSON line.  `value` = total camera paths (pixels x spp) / wall time of the K timed steps (max over
+ranks).  `roofline` prices the render kernel against what bounds it -- the SIMDs' instruction issue rate (measured:
+profiles/r02_valu_issue, profiles/r02_issue_sensitivity) -- with the HBM view (algorithmic bytes, counter traffic)
+kept beside it.  `cpu_baseline` = the oracle (a CPU port of the same path) timed on a bounded sample of the same
+frame, which doubles as a full-size parity check of those pixels.
 """
 import argparse
 import json
@@ -28,7 +29,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+SIMDS = 256 * 4                 # 256 CUs x 4 SIMD-32
+MAX_CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md "Max clock"
+ISSUE_CYCLES_PER_INST = 2.0     # a SIMD issues at most one wave64 instruction per 2 cycles (profiles/r02_valu_issue)
+ISSUE_PEAK_GINST = SIMDS * MAX_CLOCK_HZ / ISSUE_CYCLES_PER_INST / 1e9
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_c2_kernel", "pmc_rz_render_samples.json")
+INST_COUNTERS = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
+                 "SQ_INSTS_VMEM_WR", "SQ_INSTS_BRANCH")
 
 
 def parse():
@@ -39,17 +47,22 @@ def parse():
     # workload overrides (the defaults ARE the BASELINE config; anything else is for development)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per GPU")
+    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per GPU (weak scaling)")
+    ap.add_argument("--spp-total", type=int, default=0,
+                    help="fix the frame's samples per pixel whatever N is (strong scaling; 256 at N = 8 is configs[2])")
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--mesh-n", type=int, default=76, help="bunny stand-in has 12*n*n triangles")
     ap.add_argument("--backend", choices=["auto", "pixel", "wavefront"], default="auto",
                     help="render pipeline: auto = the library's default")
-    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
-                    help="nccl = RCCL over xGMI (the real thing); gloo = rehearsal of the N>1 code path on a box with "
-                         "fewer GPUs than ranks (ranks share devices, the reduce is staged through host memory)")
+    ap.add_argument("--reduce", choices=["group", "torch", "torch-gloo"], default="group",
+                    help="group = the C-ABI's rz_group (RCCL over xGMI, the product path); torch = torch.distributed.reduce on the "
+                         "ranks' device buffers (backend nccl = RCCL; also the automatic fallback if the group cannot be formed); "
+                         "torch-gloo = rehearsal of the N>1 code path on a box with fewer GPUs than ranks (ranks share devices, "
+                         "reduce staged through the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (default: min(16, usable cores) = the box's CPU share)")
-    ap.add_argument("--cpu-bands", type=int, default=18, help="oracle sample: this many 8-row bands of the frame")
+    ap.add_argument("--cpu-bands", type=int, default=36, help="oracle sample: this many 8-row bands of the frame")
+    ap.add_argument("--cpu-full-frame", action="store_true", help="also time the oracle on the WHOLE frame (about 6 s on 16 threads)")
     return ap.parse_args()
 
 
@@ -68,44 +81,83 @@ def main():
         raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    dev_index = local_rank if a.dist_backend == "nccl" else local_rank % torch.cuda.device_count()
+    use_group = world > 1 and a.reduce == "group"
+    use_nccl = world > 1 and a.reduce in ("group", "torch")
+    dev_index = local_rank if (world == 1 or use_nccl) else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if use_nccl:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # group mode: barrier + max-over-ranks only
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    from rayzen_amd import scene as S
+    from rayzen_amd import build as rzbuild
     from rayzen_amd import dist as rzdist
+    from rayzen_amd import scene as S
     from rayzen_amd.renderer import Renderer, algorithmic_bytes, frame_params
 
     W, H, bounces = a.width, a.height, a.bounces
-    spp_total = a.spp * world          # every rank renders ALL samples of its own pixels
+    spp_total = a.spp_total if a.spp_total > 0 else a.spp * world   # every rank renders ALL samples of its own pixels
+    scaling = "strong" if a.spp_total > 0 else "weak"
     sc = S.bunny_scene(n=a.mesh_n, aspect=W / H)
-    r = Renderer(dev_index, {"auto": 0, "pixel": 1, "wavefront": 2}[a.backend])
-    r.upload_scene(sc)
-    accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)    # zero outside this rank's tiles
-    stream = torch.cuda.Stream(dev)     # the kernels, the reduce and the fences all order on this stream
-    torch.cuda.set_stream(stream)
-    r.set_stream(stream.cuda_stream)
-    r.bind_accum(accum.data_ptr(), accum.numel() * 4)
+    flags = {"auto": 0, "pixel": 1, "wavefront": 2}[a.backend]
     fp = frame_params(sc.camera, W, H, len(sc.lights), bounces, spp_total, 0, rank, world)
-    r.set_frame(fp)
 
-    # N > 1: `accum` is this rank's private buffer (its non-owned pixels stay zero for ever); each step copies it to
-    # `frame` and reduces THAT in place, so rank 0's sum never leaks into the next step's input.
-    frame = torch.empty_like(accum) if world > 1 else accum
+    group = None
+    if use_group:
+        # rank 0 makes the communicator id, everybody receives it over the launcher's own process group
+        uid = torch.zeros(129, dtype=torch.uint8, device=dev)       # 128 id bytes + 1 "rank 0 could make it" flag
+        if rank == 0:
+            try:
+                uid[:128].copy_(torch.frombuffer(bytearray(rzdist.unique_id()), dtype=torch.uint8))
+                uid[128] = 1
+            except Exception as e:
+                print(f"[bench] rz_group_unique_id failed ({e}); falling back to torch.distributed.reduce", file=sys.stderr)
+        dist.broadcast(uid, 0)
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        if int(uid[128].item()) == 1:
+            try:
+                group = rzdist.Group.create_rank(dev_index, rank, world, bytes(uid[:128].cpu().numpy().tobytes()), flags)
+            except Exception as e:       # every rank must take the same way out
+                print(f"[bench] rank {rank}: rz_group_create_rank failed ({e}); falling back to torch.distributed.reduce", file=sys.stderr)
+                ok.zero_()
+        else:
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if group is not None:
+                group.close()
+            group, use_group = None, False
+    if group is not None:
+        group.upload_scene(sc)
+        group.set_frame(fp)             # tile_rank / tile_nranks are filled in by the group
+        r = group.member(0)
+        accum = frame = None
+    else:
+        r = Renderer(dev_index, flags)
+        r.upload_scene(sc)
+        accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)    # zero outside this rank's tiles
+        stream = torch.cuda.Stream(dev)     # the kernels, the reduce and the fences all order on this stream
+        torch.cuda.set_stream(stream)
+        r.set_stream(stream.cuda_stream)
+        r.bind_accum(accum.data_ptr(), accum.numel() * 4)
+        r.set_frame(fp)
+        # N > 1 rehearsal: `accum` is this rank's private buffer; each step copies it to `frame` and reduces THAT
+        frame = torch.empty_like(accum) if world > 1 else accum
 
     def step():
-        r.render()                      # async on torch's current stream
+        if group is not None:
+            group.render()                  # asynchronous on the member's stream
+            group.reduce(0)                 # ONE ncclReduce(sum) of the 33 MB frame, enqueued behind the kernel
+            return
+        r.render()
         if world > 1:
             frame.copy_(accum)
-            if a.dist_backend == "nccl":
-                rzdist.reduce_accum(frame, dst=0)          # one RCCL reduce(SUM) of the 33 MB frame
-            else:                                           # rehearsal: same reduce, staged through the host
+            if use_nccl:                    # torch path: one RCCL reduce(SUM) of the 33 MB frame
+                rzdist.reduce_accum(frame, dst=0)
+            else:                           # rehearsal: same data flow, staged through the host
                 host = frame.cpu()
                 rzdist.reduce_accum(host, dst=0)
                 if rank == 0:
@@ -114,11 +166,15 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
+        if group is not None:
+            group.sync()
         torch.cuda.synchronize(dev)
 
-    # untimed instrumented launch: exact algorithmic bytes of THIS rank's launch
+    # untimed instrumented launch: exact algorithmic unit counts of THIS rank's launch
     counters = r.render_counted()
     alg_bytes = algorithmic_bytes(counters)
+    if group is not None:
+        group.sync()
     torch.cuda.synchronize(dev)
 
     for _ in range(a.warmup):
@@ -136,62 +192,82 @@ def main():
     kms = float(np.mean(kernel_ms))
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.dist_backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if use_nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     total_samples = W * H * spp_total * a.steps
     value = total_samples / elapsed / 1e6
+    ntri = int(sc.arrays[S.BIND_TRIANGLES].shape[0])
+    cam = sc.camera
 
     out = {
         "metric": "Msamples/s (rays x spp / s) at 1080p", "value": round(value, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[1]: bunny stand-in ({sc.name}, {sc.arrays[S.BIND_TRIANGLES].shape[0]} tris "
-                               f"incl. floor) {W}x{H}, {a.spp} spp per GPU ({spp_total} spp total), {bounces} bounces, "
-                               f"2 lights", "width": W, "height": H, "spp_per_gpu": a.spp, "spp_total": spp_total,
-                   "bounces": bounces, "triangles": int(sc.arrays[S.BIND_TRIANGLES].shape[0]),
-                   "parallelism": f"tiles8x8-roundrobin-x{world}" + (("+rccl-reduce" if a.dist_backend == "nccl" else "+gloo-reduce(rehearsal)") if world > 1 else "")},
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[{2 if (world == 8 and spp_total == 256) else 1}]: bunny stand-in ({sc.name}, {ntri} tris incl. "
+                               f"floor) {W}x{H}, {spp_total} spp per frame ({spp_total // world if scaling == 'strong' else a.spp} "
+                               f"spp-equivalents of work per GPU), {bounces} bounces, 2 lights",
+                   "width": W, "height": H, "spp_per_gpu": a.spp, "spp_total": spp_total, "bounces": bounces, "triangles": ntri,
+                   # SURVEY 8(d) put the camera at (0,0,3) in front of an 8-unit mesh, i.e. INSIDE it; this is the scene used instead
+                   "camera": {"position": [float(x) for x in cam.position], "target_dir": [float(x) for x in cam.target],
+                              "fov_deg": cam.fov}, "mesh_radius": 2.8, "mesh_centre": [0.0, 2.0, 0.0],
+                   "floor": "cube scaled (8, 0.5, 8) at y = -3 (main.cpp:378)",
+                   "parallelism": f"tiles8x8-roundrobin-x{world}" + (("+rz_group-rccl-reduce" if use_group else ("+torch-rccl-reduce" if use_nccl else "+gloo-reduce(rehearsal)")) if world > 1 else "")},
     }
     if rank == 0:
+        if group is not None:
+            final = torch.from_numpy(group.read_frame())
+        else:
+            final = frame
         # size-independent check of the sharding + reduce: every pixel of the final frame received exactly
         # spp_total samples (a pixel rendered twice or not at all by the tile deal would show here)
-        cnt = frame[..., 3]
+        cnt = final[..., 3]
         out["frame_check"] = {"every_pixel_has_spp_total_samples": bool((cnt == float(spp_total)).all().item()),
-                              "finite_and_nonnegative": bool((torch.isfinite(frame).all() & (frame >= 0).all()).item())}
-        ach = alg_bytes / (kms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and world == 1:
+                              "finite_and_nonnegative": bool((torch.isfinite(final).all() & (final >= 0).all()).item())}
+        nl = max(1, len(sc.lights))
+        kernel_s = kms * 1e-3
+        out["work"] = {"camera_paths_per_launch": counters["samples"],
+                       "closest_hit_queries_per_path": round(counters["traversals"] / max(counters["samples"], 1), 3),
+                       "closest_hit_gqueries_per_s": round(counters["traversals"] / kernel_s / 1e9, 2),
+                       # lighting runs once per primary hit and fetches every light: light_fetches = lights x primary hits
+                       "primary_hit_fraction": round(counters["light_fetches"] / nl / max(counters["samples"], 1), 4),
+                       "kernel_msamples_per_s": round(counters["samples"] / kernel_s / 1e6, 2)}
+        alg_gbps = alg_bytes / kernel_s / 1e9
+        hbm = {"algorithmic_bytes_per_launch": int(alg_bytes),
+               "algorithmic_bytes_per_sample": round(alg_bytes / max(counters["samples"], 1), 1),
+               "algorithmic_GBps": round(alg_gbps, 1), "algorithmic_over_peak": round(alg_gbps / HBM_PEAK_GBPS, 3),
+               "note": "algorithmic bytes = what RayZen's shader would read from its SSBOs for this frame (SURVEY 8d), counted "
+                       "exactly by the instrumented launch; the 6 MB scene is cache resident, so this exceeds the HBM peak and "
+                       "bounds nothing -- the counter traffic below is what HBM actually moved"}
+        roof = {"bound": "inst-issue", "achieved": None, "peak": round(ISSUE_PEAK_GINST, 1), "unit": "Gwave-inst/s", "frac": None,
+                "traffic": None, "kernel": r.last_kernel_name(), "kernel_ms": round(kms, 3), "hbm": hbm,
+                "peak_note": f"{SIMDS} SIMDs x {MAX_CLOCK_HZ / 1e9} GHz / {ISSUE_CYCLES_PER_INST} cycles per wave64 instruction "
+                             "(measured issue limit of a gfx950 SIMD, vector and scalar instructions alike: profiles/r02_valu_issue)"}
+        # instruction counts and HBM traffic come from rocprofv3 --pmc passes (they cannot be read in-process); they are
+        # deterministic per (build, workload), so they are only used when they were captured from THIS build and workload
+        src_hash = rzbuild.source_hash()
+        if world == 1 and os.path.exists(PMC_JSON):
             try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == [W, H, a.spp, bounces, a.mesh_n]:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                           "note": "achieved = ALGORITHMIC bytes (what RayZen's shader reads from its SSBOs for this "
-                                   "frame, counted exactly) / kernel time; the 6 MB scene is L1/L2/scalar-cache "
-                                   "resident, so measured HBM traffic is ~230x smaller and frac may exceed 1: HBM is "
-                                   "not what bounds this kernel (VALU issue is: see DESIGN.md section 4.7)",
-                           "kernel": r.last_kernel_name(), "kernel_ms": round(kms, 3),
-                           "algorithmic_bytes_per_launch": int(alg_bytes),
-                           "algorithmic_bytes_per_sample": round(alg_bytes / max(counters["samples"], 1), 1),
-                           "kernel_msamples_per_s": round(counters["samples"] / (kms * 1e-3) / 1e6, 2)}
-        # what does bound it: the issue-side counters of the committed PMC passes (same workload), not re-measured here
-        ppath = os.path.join(ROOT, "profiles", "r01_sample_kernel_v2", "pmc_rz_render_samples.json")
-        if traffic is not None and os.path.exists(ppath):
-            try:
-                pj = json.load(open(ppath))
-                simd_cycles = pj["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
-                out["roofline"]["issue"] = {
-                    "valu_busy_frac": round(4.0 * pj["SQ_ACTIVE_INST_VALU"] / simd_cycles, 3),
-                    "valu_lane_utilisation": round(pj["SQ_THREAD_CYCLES_VALU"] / (64.0 * pj["SQ_ACTIVE_INST_VALU"]), 3),
-                    "valu_wave_instructions_per_launch": int(pj["SQ_INSTS_VALU"]),
-                    "source": "profiles/r01_sample_kernel_v2/pmc_rz_render_samples.json (rocprofv3 --pmc, separate passes)"}
-            except Exception:
-                pass
+                pj = json.load(open(PMC_JSON))
+                same = pj.get("_source_hash") == src_hash and pj.get("_workload") == [W, H, a.spp, bounces, a.mesh_n]
+                if same:
+                    insts = sum(pj[k] for k in INST_COUNTERS)
+                    ach = insts / kernel_s / 1e9
+                    traffic = int(2 * pj["FETCH_SIZE"] * 1024 + pj["WRITE_SIZE"] * 1024)   # gfx950: FETCH_SIZE under-reports wide reads 2x (MI355X_MICROARCH.md)
+                    roof.update({"achieved": round(ach, 1), "frac": round(ach / ISSUE_PEAK_GINST, 4), "traffic": traffic,
+                                 "wave_instructions_per_launch": int(insts),
+                                 "instruction_mix": {k[9:].lower(): int(pj[k]) for k in INST_COUNTERS},
+                                 "valu_lane_utilisation": round(pj["SQ_THREAD_CYCLES_VALU"] / (64.0 * pj["SQ_ACTIVE_INST_VALU"]), 3),
+                                 "counters_from": os.path.relpath(PMC_JSON, ROOT), "counters_source_hash": src_hash[:16]})
+                    hbm.update({"counter_traffic_GBps": round(traffic / kernel_s / 1e9, 1),
+                                "counter_traffic_over_peak": round(traffic / kernel_s / 1e9 / HBM_PEAK_GBPS, 4)})
+                else:
+                    roof["counters_stale"] = (f"{os.path.relpath(PMC_JSON, ROOT)} was captured from another build or workload "
+                                              f"(hash {str(pj.get('_source_hash'))[:16]} vs {src_hash[:16]}): not used")
+            except Exception as e:      # a malformed profile must not take the benchmark down
+                roof["counters_stale"] = f"cannot read {PMC_JSON}: {e}"
+        out["roofline"] = roof
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import rzo
         from helpers import oracle_frame, oracle_scene
@@ -200,35 +276,45 @@ def main():
         ofr = oracle_frame(sc, W, H, a.spp, bounces)
         ref = np.zeros((H, W, 4), np.float32)
         nb = max(1, a.cpu_bands)
-        rows = 0
-        t_cpu = 0.0
-        bands = []
+        rows, t_cpu, bands, busy = 0, 0.0, [], ncores
         for b in range(nb):
             y0 = min(H - 8, int((b + 0.5) * H / nb) // 8 * 8)
+            if y0 in bands:
+                continue
             tc = time.perf_counter()
-            rzo.render(osc, ofr, accum=ref, crop=(0, y0, W, y0 + 8), nthreads=ncores)
+            rzo.render(osc, ofr, accum=ref, crop=(0, y0, W, y0 + 8), nthreads=ncores)   # work is handed out in 16-pixel chunks
             t_cpu += time.perf_counter() - tc
+            busy = min(busy, rzo.last_threads_busy())
             rows += 8
             bands.append(y0)
         cpu_samples = rows * W * a.spp
-        gpu = frame.cpu().numpy()       # last timed frame (sample_base 0 each step: a complete frame)
-        err = 0.0
-        same = 0
-        tot = 0
+        gpu = final.cpu().numpy()       # last timed frame (sample_base 0 each step: a complete frame)
+        err, same, tot = 0.0, 0, 0
         for y0 in bands:
             g, o = gpu[y0:y0 + 8], ref[y0:y0 + 8]
             err = max(err, float(np.abs(g.astype(np.float64) - o.astype(np.float64)).max()))
             same += int((g.view(np.uint32) == o.view(np.uint32)).all(axis=-1).sum())
             tot += g.shape[0] * g.shape[1]
-        out["cpu_baseline"] = {"value": round(cpu_samples / t_cpu / 1e6, 4), "unit": "Msamples/s", "cores": ncores,
+        cpu_rate = cpu_samples / t_cpu / 1e6
+        out["cpu_baseline"] = {"value": round(cpu_rate, 4), "unit": "Msamples/s", "cores": ncores, "threads_busy": busy,
                                "kind": "port",
-                               "sample": f"{nb} full-width 8-row bands of the same {W}x{H}x{a.spp}spp frame "
-                                         f"({cpu_samples} of {W * H * a.spp} camera paths, {t_cpu:.1f} s)",
-                               "gpu_over_cpu": round(value / (cpu_samples / t_cpu / 1e6), 1)}
+                               "sample": f"{len(bands)} full-width 8-row bands of the same {W}x{H}x{a.spp}spp frame "
+                                         f"({cpu_samples} of {W * H * a.spp} camera paths, {t_cpu:.1f} s wall on {ncores} threads = "
+                                         f"{t_cpu * ncores:.0f} core-seconds)",
+                               "gpu_over_cpu": round(value / cpu_rate, 1)}
+        if a.cpu_full_frame:
+            tc = time.perf_counter()
+            full = rzo.render(osc, ofr, nthreads=ncores)
+            tf = time.perf_counter() - tc
+            out["cpu_baseline"]["full_frame"] = {"value": round(W * H * a.spp / tf / 1e6, 4), "seconds": round(tf, 2),
+                                                 "bit_identical_to_gpu": bool((full.view(np.uint32) == gpu.view(np.uint32)).all())}
         out["parity"] = {"linf_vs_oracle_on_sample": err, "bit_identical_pixels": same, "pixels_compared": tot}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    r.close()
+    if group is not None:
+        group.close()
+    else:
+        r.close()
     if world > 1:
         dist.destroy_process_group()
 

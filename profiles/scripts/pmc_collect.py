@@ -35,6 +35,11 @@ def main():
     args, cmd = sys.argv[1:k], sys.argv[k + 1:]
     out_json, kernel = args[0], args[1]
     groups = DEFAULT_GROUPS
+    workload = None
+    if "--workload" in args:            # e.g. --workload 1920,1080,64,4,76  (recorded as _workload; bench.py matches on it)
+        i = args.index("--workload")
+        workload = [int(x) for x in args[i + 1].split(",")]
+        del args[i:i + 2]
     if "--groups" in args:
         groups = [g.replace(",", " ") for g in args[args.index("--groups") + 1:]]
     tmp_root = os.path.join(os.path.dirname(os.path.abspath(out_json)) or ".", "_pmc_tmp")
@@ -66,8 +71,15 @@ def main():
                         "duration_ns_under_profiler": int(row["End_Timestamp"]) - int(row["Start_Timestamp"])}
     summary["_dispatch"] = meta
     summary["_command"] = " ".join(cmd)
+    summary["_workload"] = workload
+    try:                                 # which build the counters belong to (rayzen_amd/build.py: source_hash)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+        from rayzen_amd import build as rzbuild
+        summary["_source_hash"] = rzbuild.source_hash()
+    except Exception as e:
+        summary["_source_hash"] = f"unavailable: {e}"
     json.dump(summary, open(out_json, "w"), indent=1)
-    print(f"[pmc] wrote {out_json}: {len(summary) - 2} counters", flush=True)
+    print(f"[pmc] wrote {out_json}: {sum(1 for k in summary if not k.startswith('_'))} counters", flush=True)
     shutil.rmtree(tmp_root, ignore_errors=True)
 
 

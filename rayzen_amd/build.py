@@ -75,10 +75,25 @@ def build_host(force=False, verbose=False):
     return HOST_SO
 
 
+def source_hash():
+    """sha256 over everything librayzen_hip.so is built from (sources, headers, flags): ties a committed rocprofv3
+    counter file (profiles/) to the build it was captured from."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in _files(HIP_DIR, (".hip", ".h")) + _files(INC, (".h",)):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
 def build_all(force=False, verbose=False):
     return build_host(force, verbose), build_hip(force, verbose)
 
 
 if __name__ == "__main__":
+    if "--hash" in sys.argv:
+        print(source_hash())
+        sys.exit(0)
     build_all(force="--force" in sys.argv, verbose=True)
     print("built", HOST_SO, HIP_SO)

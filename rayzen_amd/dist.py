@@ -166,11 +166,17 @@ class Group:
         return self._L.rz_group_frame_device_ptr(self._g)
 
     def member(self, local=0):
-        """A Renderer view of one member's context (per-device calls: counters, timings); does not own it."""
+        """A Renderer view of one member's context (per-device calls: counters, timings).  The group owns the context:
+        closing or dropping the view does nothing."""
         from .renderer import Renderer
-        r = Renderer.__new__(Renderer)
-        r._L = self._L
-        r._c = self._L.rz_group_ctx(self._g, int(local))
-        r.width, r.height = self.width, self.height
-        r.close = lambda: None          # the group owns the context
-        return r
+
+        class _MemberView(Renderer):
+            def __init__(view, L, c, w, h):     # noqa: N805
+                view._L, view._c, view.width, view.height = L, c, w, h
+
+            def close(view):                    # noqa: N805
+                view._c = None
+
+            __del__ = close
+
+        return _MemberView(self._L, self._L.rz_group_ctx(self._g, int(local)), self.width, self.height)
