@@ -63,6 +63,15 @@ void rzh_scene_depths(const rzh_scene* s, int* max_blas_depth, int* tlas_depth);
  * order as the cached instances).  0 on success, -1 on any I/O or consistency failure. */
 int rzh_scene_save_cache(const rzh_scene* s, const char* dir);
 int rzh_scene_load_cache(rzh_scene* s, const char* dir);
+/* initializeSSBOs with RayZen's whole disk cache, step for step (src/main.cpp:897-1060): the ssbo_v2_* set (invalidated
+ * only by a changed object count, main.cpp:929-934; transforms refreshed on use, main.cpp:1054-1060), else per object
+ * `mesh<i>.nodes.bin` / `mesh<i>.tris.bin` (saveBVHToFile / loadBVHFromFile, main.cpp:117-125, 956-967), then
+ * `scene_tlas.nodes.bin` / `.tris.bin` + `instances.bin` (main.cpp:1012-1026, used only if every BLAS came from the cache);
+ * what was built is written back and the ssbo_v2_* set rewritten.  `dir` stands for "bvh_cache/v2/" and is created if
+ * missing; force_rebuild = the --rebuild-bvh flag.  One BLAS + triangle copy per object, as the reference does.
+ * report (may be NULL): {ssbo set used, ssbo set invalidated, BLAS loaded, BLAS built, TLAS+instances loaded}.
+ * 0 on success, -2 if the device BLAS builder failed. */
+int rzh_scene_build_cached(rzh_scene* s, const char* dir, int force_rebuild, int report[5]);
 
 /* Camera (include/Camera.h:42-48) + the inverses sendSceneDataToShader
  * uploads (src/main.cpp:1363-1364).  target is a direction. All column-major. */

@@ -27,7 +27,7 @@ HOST_SYMBOLS = (
     "rzh_load_obj", "rzh_build_blas", "rzh_build_tlas", "rzh_world_bounds", "rzh_scene_create",
     "rzh_scene_destroy", "rzh_scene_add_mesh", "rzh_scene_add_object", "rzh_scene_set_transform",
     "rzh_scene_build", "rzh_scene_set_blas_builder", "rzh_scene_update_dynamic", "rzh_scene_buffer", "rzh_scene_depths",
-    "rzh_scene_save_cache", "rzh_scene_load_cache",
+    "rzh_scene_save_cache", "rzh_scene_load_cache", "rzh_scene_build_cached",
     "rzh_camera_matrices", "rzh_mat_translate", "rzh_mat_scale", "rzh_mat_rotate", "rzh_mat_inverse",
     "rzh_make_cube", "rzh_make_blob", "rzh_version",
 )
@@ -144,6 +144,7 @@ def host():
         L.rzh_scene_buffer.restype, L.rzh_scene_buffer.argtypes = vp, [vp, i, C.POINTER(sz)]
         L.rzh_scene_save_cache.restype, L.rzh_scene_save_cache.argtypes = i, [vp, C.c_char_p]
         L.rzh_scene_load_cache.restype, L.rzh_scene_load_cache.argtypes = i, [vp, C.c_char_p]
+        L.rzh_scene_build_cached.restype, L.rzh_scene_build_cached.argtypes = i, [vp, C.c_char_p, i, C.POINTER(i * 5)]
         L.rzh_scene_depths.restype, L.rzh_scene_depths.argtypes = None, [vp, C.POINTER(i), C.POINTER(i)]
         L.rzh_camera_matrices.restype = None
         L.rzh_camera_matrices.argtypes = [vp, vp, vp, f, f, f, f, vp, vp, vp, vp]

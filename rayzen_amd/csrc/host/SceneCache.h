@@ -49,4 +49,28 @@ bool loadVectorFromFile(const std::string& filename, std::vector<T>& vec) {
 bool saveSceneCache(const std::string& dir, const SceneBuffers& b);
 bool loadSceneCache(const std::string& dir, SceneBuffers& b);
 
+// saveBVHToFile / loadBVHFromFile (main.cpp:117-125): <base>.nodes.bin + <base>.tris.bin
+bool saveBVHToFile(const std::string& base, const BVH& bvh);
+bool loadBVHFromFile(const std::string& base, BVH& bvh);
+
+// What initializeSSBOs (main.cpp:897-1060) found on disk.
+struct CacheReport {
+    bool ssboLoaded = false;        // the six ssbo_v2_* files were used (main.cpp:914-939)
+    bool ssboInvalidated = false;   // ... they were there, but the object count had changed (main.cpp:929-934)
+    int blasLoaded = 0;             // meshes whose mesh<i>.nodes.bin / .tris.bin were used (main.cpp:956-961)
+    int blasBuilt = 0;              // meshes built from scratch (and written back, main.cpp:962-967)
+    bool tlasLoaded = false;        // scene_tlas.* + instances.bin were used (main.cpp:1012-1018)
+};
+
+// initializeSSBOs WITH RayZen's disk cache, step for step (main.cpp:897-1060), including its quirks:
+//  * the ssbo_v2_* set is invalidated only by a changed object COUNT; when it is used, transforms / inverses / mesh
+//    indices are refreshed from the scene (main.cpp:1054-1060) but the cached TLAS is kept as it is;
+//  * a BLAS is cached per OBJECT index (mesh<i>), every object gets its own copy of its mesh (no sharing);
+//  * scene_tlas.* + instances.bin are used only if every BLAS came from the cache, and loading instances.bin replaces
+//    the instance records just assembled -- transforms included -- with the cached ones;
+//  * whatever was built is written back, then the ssbo_v2_* set is written.
+// `dir` plays the role of "bvh_cache/v2/" (created if missing).  false only on a failed BLAS builder.
+bool initializeSSBOsCached(const Scene& scene, const std::string& dir, bool forceRebuildBVH, SceneBuffers& out,
+                           CacheReport* report = nullptr);
+
 }  // namespace rayzen

@@ -152,6 +152,18 @@ int rzh_scene_load_cache(rzh_scene* s, const char* dir) {
     return 0;
 }
 
+int rzh_scene_build_cached(rzh_scene* s, const char* dir, int force_rebuild, int report[5]) {
+    if (!s || !dir) return -1;
+    CacheReport rep;
+    if (!initializeSSBOsCached(s->scene, dir, force_rebuild != 0, s->buffers, &rep)) { s->built = false; return -2; }
+    s->built = true;
+    if (report) {
+        report[0] = rep.ssboLoaded; report[1] = rep.ssboInvalidated; report[2] = rep.blasLoaded; report[3] = rep.blasBuilt;
+        report[4] = rep.tlasLoaded;
+    }
+    return 0;
+}
+
 void rzh_scene_depths(const rzh_scene* s, int* max_blas_depth, int* tlas_depth) {
     if (max_blas_depth) *max_blas_depth = s ? s->buffers.maxBLASDepth : 0;
     if (tlas_depth) *tlas_depth = s ? s->buffers.tlasDepth : 0;

@@ -267,6 +267,19 @@ class Scene:
         self._pull(GEOMETRY_BINDINGS)
         return self
 
+    def build_cached(self, directory, force_rebuild=False):
+        """initializeSSBOs with RayZen's whole disk cache (main.cpp:897-1060): `directory` stands for bvh_cache/v2/.
+        Returns what was found: dict(ssbo_loaded, ssbo_invalidated, blas_loaded, blas_built, tlas_loaded)."""
+        import os
+        rep = (C.c_int * 5)()
+        rc = _lib.host().rzh_scene_build_cached(self._h, os.fsencode(directory), 1 if force_rebuild else 0, C.byref(rep))
+        if rc != 0:
+            raise RuntimeError(f"rzh_scene_build_cached failed ({rc})")
+        self._pull(GEOMETRY_BINDINGS)
+        self.cache_report = dict(ssbo_loaded=bool(rep[0]), ssbo_invalidated=bool(rep[1]), blas_loaded=rep[2],
+                                 blas_built=rep[3], tlas_loaded=bool(rep[4]))
+        return self
+
     def update_dynamic(self):
         if _lib.host().rzh_scene_update_dynamic(self._h) != 0:
             raise RuntimeError("rzh_scene_update_dynamic failed")

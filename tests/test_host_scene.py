@@ -182,3 +182,113 @@ def test_blas_builder_hook_is_used_and_its_failure_is_reported():
     s.build()
     for b in S.GEOMETRY_BINDINGS:
         assert s.arrays[b].tobytes() == ref.arrays[b].tobytes()
+
+
+def _dynamic_scene(transforms):
+    """floor + one blob instance per transform (each object its own mesh copy: the reference never shares)."""
+    sc = S.Scene()
+    floor, blob = sc.add_mesh(S.make_cube(4)), sc.add_mesh(S.make_blob(4, 2.8, 0))
+    sc.add_object(floor, S.translate(S.scale(S.identity(), (8.0, 0.5, 8.0)), (0.0, -3.0, 0.0)))
+    for t in transforms:
+        sc.add_object(blob, t)
+    return sc
+
+
+def _files(d):
+    return sorted(os.listdir(d))
+
+
+def test_full_disk_cache_flow_of_initializeSSBOs(tmp_path):
+    """RayZen/src/main.cpp:897-1060, step for step: the ssbo_v2_* set, per-object mesh<i>.nodes/.tris, scene_tlas.* +
+    instances.bin, all `size_t count + raw POD`; what is on disk decides what is rebuilt."""
+    import struct
+    d = str(tmp_path / "bvh_cache" / "v2")
+    xf = S.instanced_transforms(0, 3)
+    ref = _dynamic_scene(xf).build(share_meshes=False)              # no cache: the expected arrays
+    first = _dynamic_scene(xf).build_cached(d)
+    assert first.cache_report == dict(ssbo_loaded=False, ssbo_invalidated=False, blas_loaded=0, blas_built=4, tlas_loaded=False)
+    for b in S.GEOMETRY_BINDINGS:
+        assert first.arrays[b].tobytes() == ref.arrays[b].tobytes(), b
+    want = ["instances.bin", "scene_tlas.nodes.bin", "scene_tlas.tris.bin"]
+    want += [f"mesh{i}.{k}.bin" for i in range(4) for k in ("nodes", "tris")]
+    want += [f"ssbo_v2_{n}.bin" for n in ("triangles", "blasnodes", "blastris", "instances", "tlasnodes", "tlastris")]
+    assert _files(d) == sorted(want)
+    # byte layout of the per-mesh / TLAS / instance files (main.cpp:94-133)
+    inst = ref.arrays[S.BIND_INSTANCES]
+    bn, bi = ref.arrays[S.BIND_BLAS_NODES], ref.arrays[S.BIND_BLAS_INDICES]
+    for i in range(4):
+        n0 = int(inst["blasNodeOffset"][i]); n1 = int(inst["blasNodeOffset"][i + 1]) if i < 3 else len(bn)
+        t0 = int(inst["blasTriOffset"][i]); t1 = int(inst["blasTriOffset"][i + 1]) if i < 3 else len(bi)
+        raw = open(os.path.join(d, f"mesh{i}.nodes.bin"), "rb").read()
+        assert struct.unpack("<Q", raw[:8])[0] == n1 - n0 and raw[8:] == bn[n0:n1].tobytes()
+        raw = open(os.path.join(d, f"mesh{i}.tris.bin"), "rb").read()
+        assert struct.unpack("<Q", raw[:8])[0] == t1 - t0 and raw[8:] == bi[t0:t1].tobytes()
+    raw = open(os.path.join(d, "scene_tlas.nodes.bin"), "rb").read()
+    assert raw[8:] == ref.arrays[S.BIND_TLAS_NODES].tobytes()
+    raw = open(os.path.join(d, "scene_tlas.tris.bin"), "rb").read()
+    assert raw[8:] == ref.arrays[S.BIND_TLAS_INDICES].tobytes()
+    raw = open(os.path.join(d, "instances.bin"), "rb").read()
+    assert struct.unpack("<Q", raw[:8])[0] == 4 and raw[8:] == inst.tobytes() and len(raw) == 8 + 4 * 144
+
+    # second start: the ssbo set is used, nothing is built
+    again = _dynamic_scene(xf).build_cached(d)
+    assert again.cache_report["ssbo_loaded"] and again.cache_report["blas_built"] == 0
+    for b in S.GEOMETRY_BINDINGS:
+        assert again.arrays[b].tobytes() == ref.arrays[b].tobytes(), b
+    assert (again.max_blas_depth, again.tlas_depth) == (ref.max_blas_depth, ref.tlas_depth)
+
+    # ssbo set gone: every BLAS + the TLAS + the instances come from their own files, and the ssbo set is rewritten
+    for f in _files(d):
+        if f.startswith("ssbo_v2_"):
+            os.remove(os.path.join(d, f))
+    third = _dynamic_scene(xf).build_cached(d)
+    assert third.cache_report == dict(ssbo_loaded=False, ssbo_invalidated=False, blas_loaded=4, blas_built=0, tlas_loaded=True)
+    for b in S.GEOMETRY_BINDINGS:
+        assert third.arrays[b].tobytes() == ref.arrays[b].tobytes(), b
+    assert "ssbo_v2_triangles.bin" in _files(d)
+
+    # --rebuild-bvh ignores everything on disk
+    forced = _dynamic_scene(xf).build_cached(d, force_rebuild=True)
+    assert forced.cache_report == dict(ssbo_loaded=False, ssbo_invalidated=False, blas_loaded=0, blas_built=4, tlas_loaded=False)
+
+
+def test_disk_cache_invalidation_and_the_reference_s_stale_data_quirks(tmp_path):
+    d = str(tmp_path / "c")
+    xf = S.instanced_transforms(0, 3)
+    _dynamic_scene(xf).build_cached(d)
+    # (1) a changed object COUNT is the only thing that invalidates the ssbo set (main.cpp:929-934); the BLAS of the
+    #     objects that still exist come from their mesh<i> files, the new object's is built, the TLAS is rebuilt
+    xf4 = S.instanced_transforms(0, 4)
+    grown = _dynamic_scene(xf4).build_cached(d)
+    assert grown.cache_report == dict(ssbo_loaded=False, ssbo_invalidated=True, blas_loaded=4, blas_built=1, tlas_loaded=False)
+    fresh = _dynamic_scene(xf4).build(share_meshes=False)
+    for b in S.GEOMETRY_BINDINGS:
+        assert grown.arrays[b].tobytes() == fresh.arrays[b].tobytes(), b
+    # (2) same count, moved objects, ssbo set present: transforms / inverses are refreshed from the scene
+    #     (main.cpp:1054-1060) but the cached TLAS is used as it is -- stale, exactly like the reference
+    moved = S.instanced_transforms(9, 4)
+    stale = _dynamic_scene(moved).build_cached(d)
+    assert stale.cache_report["ssbo_loaded"]
+    want = _dynamic_scene(moved).build(share_meshes=False)
+    assert stale.arrays[S.BIND_INSTANCES].tobytes() == want.arrays[S.BIND_INSTANCES].tobytes()
+    assert stale.arrays[S.BIND_TLAS_NODES].tobytes() == grown.arrays[S.BIND_TLAS_NODES].tobytes()      # the OLD boxes
+    assert stale.arrays[S.BIND_TLAS_NODES].tobytes() != want.arrays[S.BIND_TLAS_NODES].tobytes()
+    # (3) ssbo set gone, all BLAS cached: scene_tlas + instances.bin are loaded, and instances.bin REPLACES the records
+    #     just assembled, transforms included (main.cpp:1013: loadBVHInstancesFromFile into meshInstances)
+    for f in _files(d):
+        if f.startswith("ssbo_v2_"):
+            os.remove(os.path.join(d, f))
+    old = _dynamic_scene(moved).build_cached(d)
+    assert old.cache_report["tlas_loaded"] and old.cache_report["blas_loaded"] == 5
+    assert old.arrays[S.BIND_INSTANCES].tobytes() == grown.arrays[S.BIND_INSTANCES].tobytes()          # the OLD transforms
+    # (4) a truncated per-mesh file is not trusted: that BLAS is rebuilt, and then the TLAS is too
+    p = os.path.join(d, "mesh2.nodes.bin")
+    raw = open(p, "rb").read()
+    open(p, "wb").write(raw[:len(raw) // 2])
+    for f in _files(d):
+        if f.startswith("ssbo_v2_"):
+            os.remove(os.path.join(d, f))
+    healed = _dynamic_scene(moved).build_cached(d)
+    assert healed.cache_report == dict(ssbo_loaded=False, ssbo_invalidated=False, blas_loaded=4, blas_built=1, tlas_loaded=False)
+    for b in S.GEOMETRY_BINDINGS:
+        assert healed.arrays[b].tobytes() == want.arrays[b].tobytes(), b
