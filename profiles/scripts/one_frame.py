@@ -1,4 +1,5 @@
-"""Two C2 frames with the default kernel (for rocprofv3 passes that should not pay for bench.py's extras)."""
+"""Two frames of one BASELINE configuration with the default kernel (for rocprofv3 passes that should not pay for
+bench.py's extras):  one_frame.py [c2|c4|c5]   (c2 is the bench workload; c5 at 32 spp keeps counter passes short)."""
 import os
 import sys
 
@@ -6,13 +7,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from rayzen_amd import scene as S
 from rayzen_amd.renderer import Renderer, frame_params
 
-W, H, SPP, B = 1920, 1080, 64, 4
-sc = S.bunny_scene(n=76, aspect=W / H)
+which = sys.argv[1] if len(sys.argv) > 1 else "c2"
+if which == "c2":
+    W, H, SPP, B = 1920, 1080, 64, 4
+    sc = S.bunny_scene(n=76, aspect=W / H)
+elif which == "c4":
+    W, H, SPP, B = 1920, 1080, 16, 4
+    sc = S.instanced_scene(n=76, count=16, aspect=W / H)
+elif which == "c5":
+    W, H, SPP, B = 3840, 2160, 32, 8
+    sc = S.stress_scene(n=289, aspect=W / H)
+else:
+    raise SystemExit(which)
 r = Renderer(0)
 r.upload_scene(sc)
 r.set_frame(frame_params(sc.camera, W, H, len(sc.lights), B, SPP))
 for _ in range(2):
     r.render()
 r.sync()
-print([round(x, 2) for x in r.render_history_ms()])
+print(which, [round(x, 2) for x in r.render_history_ms()])
 r.close()
