@@ -153,6 +153,7 @@ typedef struct rz_ctx rz_ctx;
 #define RZ_FLAG_NONE          0u  /* default: one lane per sample (rz_render_samples)                         */
 #define RZ_FLAG_MEGAKERNEL    1u  /* one lane per pixel, samples in sequence (rz_render_pixels): cross-check  */
 #define RZ_FLAG_WAVEFRONT     2u  /* queued pipeline wf_init/wf_trace/wf_shade: bit-identical, slower, opt-in */
+#define RZ_FLAG_HOST_RELAYOUT 4u  /* re-lay the scene out on the host instead of on the device (same bytes; cross-check) */
 rz_ctx*     rz_create(int device, unsigned flags);
 void        rz_destroy(rz_ctx* ctx);
 const char* rz_last_error(const rz_ctx* ctx);
@@ -315,6 +316,10 @@ int rz_group_sync(rz_group* g);                                 /* glFinish on e
 int rz_group_read_frame(rz_group* g, float* rgba, size_t bytes);
 /* Device pointer of the reduced frame on the root member (NULL in other processes). */
 void* rz_group_frame_device_ptr(rz_group* g);
+
+/* TEST HOOK: the device-side scene layout as built (which = 0: DevPair[] 64 B each, 1: DevTri[] 48 B each;
+ * rayzen_amd/csrc/hip/rz_scene_dev.h).  out NULL: only *needed is set.  Runs the pending re-layout first. */
+int rz_debug_read_layout(rz_ctx* ctx, int which, void* out, size_t bytes, size_t* needed);
 
 /* Number of HIP devices visible to the process (0 without a GPU). */
 int rz_device_count(void);

@@ -44,6 +44,16 @@ SamplesPlan plan_render_samples(int spp, int nSlots);
 size_t samples_lds_extra(bool glass);
 void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream_t stream);
 void launch_resolve(const float4* accum, uchar4* out, int n, hipStream_t stream);
+struct RelayoutView {        // rz_relayout.hip
+    int nodeOff, triOff, gTriOff; int pairBase, triBase; int nPairs, nSlots, depth, rootEnc, empty; float rootMin[3], rootMax[3];
+};
+size_t relayout_workspace_bytes(size_t nNodes);
+int relayout_view_device(const rz_bvh_node* nodes, long long nNodes, const int32_t* idx, long long nIdx, const rz_triangle* tris,
+                         long long nTris, const rz_material* mats, int nMat, const rz_bvh_node& hostRoot, RelayoutView& V,
+                         DevPair* pairs, long long pairCap, DevTri* trisOut, long long triCap, void* workspace, size_t workspaceBytes,
+                         int* pinned, unsigned* transparentOut, hipStream_t s);
+int relayout_check_materials_device(const DevTri* tris, long long n, const rz_material* mats, int nMat, void* workspace, int* pinned,
+                                    unsigned* transparentOut, int* detail, hipStream_t s);
 struct PresentParams {      // rz_present.hip
     const float4* accum; uchar4* rgba8; float* rgb; const TlasNode* tlasNodes; const int32_t* tlasIndices;
     const DevInstance* instances; const DevLight* lights; int width, height; int nTlasNodes, nInstances, nLights;
@@ -140,6 +150,12 @@ struct rz_ctx {
     void* extAccum = nullptr;
     size_t extAccumBytes = 0;
     int failAllocCountdown = 0;         // rz_debug_fail_alloc (test hook)
+    // device re-layout (rz_relayout.hip): the caller's raw arrays on the device, the fill of dPairs / dTris, scratch
+    DevBuf dRawNodes, dRawIdx, dRawTris, dRelayoutWs;
+    int* relayoutPinned = nullptr;
+    bool layoutOnDevice = false;        // dPairs / dTris were produced on the device (hPairs / hTris are empty)
+    long long devPairsUsed = 0, devTrisUsed = 0;
+    unsigned devTransparent = 0;
 };
 
 namespace {
@@ -329,31 +345,113 @@ int tlas_depth(const rz_bvh_node* n, size_t count) {
     return best;
 }
 
+// Device re-layout of one view (rz_relayout.hip).  RZ_OK: V filled; 1: the arrays are inconsistent or something did
+// not fit -- run the host re-layout, which words the error; other negatives: a HIP failure.
+bool host_relayout_forced(const rz_ctx* c) {
+    if (c->flags & RZ_FLAG_HOST_RELAYOUT) return true;
+    const char* e = std::getenv("RZ_HOST_RELAYOUT");
+    return e && *e && *e != '0';
+}
+
+int prepare_device_relayout(rz_ctx* c) {       // raw arrays + materials on the device, output buffers sized, scratch
+    const size_t nNodes = hostCount<rz_bvh_node>(c, RZ_BIND_BLAS_NODES), nIdx = hostCount<int32_t>(c, RZ_BIND_BLAS_INDICES);
+    int rc = upload_vec(c, c->dRawNodes, c->host[RZ_BIND_BLAS_NODES].data(), c->host[RZ_BIND_BLAS_NODES].size());
+    if (rc != RZ_OK) return rc;
+    rc = upload_vec(c, c->dRawIdx, c->host[RZ_BIND_BLAS_INDICES].data(), c->host[RZ_BIND_BLAS_INDICES].size());
+    if (rc != RZ_OK) return rc;
+    rc = upload_vec(c, c->dRawTris, c->host[RZ_BIND_TRIANGLES].data(), c->host[RZ_BIND_TRIANGLES].size());
+    if (rc != RZ_OK) return rc;
+    rc = ensure(c, c->dPairs, std::max<size_t>(nNodes, 1) * sizeof(DevPair));
+    if (rc != RZ_OK) return rc;
+    rc = ensure(c, c->dTris, std::max<size_t>(nIdx, 1) * sizeof(DevTri));
+    if (rc != RZ_OK) return rc;
+    rc = ensure(c, c->dRelayoutWs, relayout_workspace_bytes(nNodes));
+    if (rc != RZ_OK) return rc;
+    if (!c->relayoutPinned) RZ_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->relayoutPinned), 64, hipHostMallocDefault));
+    return RZ_OK;
+}
+
+int device_view(rz_ctx* c, int nodeOff, int triOff, int gTriOff, BlasView& V) {
+    const long long nNodes = (long long)hostCount<rz_bvh_node>(c, RZ_BIND_BLAS_NODES);
+    const long long nIdx = (long long)hostCount<int32_t>(c, RZ_BIND_BLAS_INDICES);
+    const long long nTris = (long long)hostCount<rz_triangle>(c, RZ_BIND_TRIANGLES);
+    if (nodeOff < 0 || nodeOff >= nNodes) return 1;
+    RelayoutView R{};
+    R.nodeOff = nodeOff; R.triOff = triOff; R.gTriOff = gTriOff;
+    R.pairBase = (int)c->devPairsUsed; R.triBase = (int)c->devTrisUsed;
+    const int rc = relayout_view_device(static_cast<const rz_bvh_node*>(c->dRawNodes.p), nNodes, static_cast<const int32_t*>(c->dRawIdx.p), nIdx,
+                                        static_cast<const rz_triangle*>(c->dRawTris.p), nTris, static_cast<const rz_material*>(c->dMat.p),
+                                        (int)hostCount<rz_material>(c, RZ_BIND_MATERIALS), hostArr<rz_bvh_node>(c, RZ_BIND_BLAS_NODES)[nodeOff], R,
+                                        static_cast<DevPair*>(c->dPairs.p), (long long)(c->dPairs.cap / sizeof(DevPair)),
+                                        static_cast<DevTri*>(c->dTris.p), (long long)(c->dTris.cap / sizeof(DevTri)), c->dRelayoutWs.p,
+                                        c->dRelayoutWs.cap, c->relayoutPinned, &c->devTransparent, c->stream);
+    if (rc < 0) return fail(c, RZ_ERR_HIP, "device re-layout: %s", hipGetErrorString((hipError_t)(-rc)));
+    if (rc > 0) return 1;
+    V.pairBase = R.pairBase; V.triBase = R.triBase; V.rootEnc = R.rootEnc; V.depth = R.depth; V.empty = R.empty != 0;
+    std::memcpy(V.rootMin, R.rootMin, 12); std::memcpy(V.rootMax, R.rootMax, 12);
+    c->devPairsUsed += R.nPairs; c->devTrisUsed += R.nSlots;
+    return RZ_OK;
+}
+
 int finalize_body(rz_ctx* c) {
     if (!(c->geomDirty || c->instDirty || c->tlasDirty || c->matDirty || c->lightDirty)) return RZ_OK;
     for (int b : {RZ_BIND_TRIANGLES, RZ_BIND_MATERIALS, RZ_BIND_LIGHTS, RZ_BIND_TLAS_NODES, RZ_BIND_TLAS_INDICES,
                   RZ_BIND_BLAS_NODES, RZ_BIND_BLAS_INDICES, RZ_BIND_INSTANCES})
         if (!c->present[b]) return fail(c, RZ_ERR_NOT_READY, "binding %d has not been uploaded", b);
 
-    if (c->geomDirty) { c->views.clear(); c->hPairs.clear(); c->hTris.clear(); c->instDirty = true; }
+    // materials first: the device re-layout checks triangle material indices against them
+    if (c->matDirty) {
+        int rc = upload_vec(c, c->dMat, c->host[RZ_BIND_MATERIALS].data(), c->host[RZ_BIND_MATERIALS].size());
+        if (rc != RZ_OK) return rc;
+    }
+    if (c->geomDirty) {
+        c->views.clear(); c->hPairs.clear(); c->hTris.clear(); c->instDirty = true;
+        c->devPairsUsed = c->devTrisUsed = 0; c->devTransparent = 0;
+        c->layoutOnDevice = !host_relayout_forced(c);
+        if (c->layoutOnDevice) { int rc = prepare_device_relayout(c); if (rc != RZ_OK) return rc; }
+    }
     if (c->instDirty) {
         const rz_bvh_instance* inst = hostArr<rz_bvh_instance>(c, RZ_BIND_INSTANCES);
         const size_t nInst = hostCount<rz_bvh_instance>(c, RZ_BIND_INSTANCES);
         alloc_point(c);
         std::vector<DevInstance> dev(nInst);
-        bool grew = false;
-        c->maxBlasDepth = 1;
-        for (size_t i = 0; i < nInst; ++i) {
-            auto key = std::make_tuple(inst[i].blasNodeOffset, inst[i].blasTriOffset, inst[i].globalTriOffset);
-            auto it = c->views.find(key);
-            if (it == c->views.end()) {
+        // Pass 1: lay out every BLAS view the instances name that is not laid out yet -- on the device
+        // (rz_relayout.hip), or, if that finds the arrays inconsistent (or is switched off), on the host, which
+        // also words the error.
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            bool redo = false, grew = false;
+            for (size_t i = 0; i < nInst && !redo; ++i) {
+                auto key = std::make_tuple(inst[i].blasNodeOffset, inst[i].blasTriOffset, inst[i].globalTriOffset);
+                if (c->views.find(key) != c->views.end()) continue;
                 BlasView V;
-                int rc = build_view(c, inst[i].blasNodeOffset, inst[i].blasTriOffset, inst[i].globalTriOffset, V);
+                int rc;
+                if (c->layoutOnDevice) {
+                    rc = device_view(c, inst[i].blasNodeOffset, inst[i].blasTriOffset, inst[i].globalTriOffset, V);
+                    if (rc == 1) {          // start over on the host
+                        c->layoutOnDevice = false;
+                        c->views.clear(); c->hPairs.clear(); c->hTris.clear();
+                        redo = true;
+                        break;
+                    }
+                } else {
+                    rc = build_view(c, inst[i].blasNodeOffset, inst[i].blasTriOffset, inst[i].globalTriOffset, V);
+                }
                 if (rc != RZ_OK) { c->views.clear(); c->hPairs.clear(); c->hTris.clear(); c->geomDirty = true; return rc; }
-                it = c->views.emplace(key, V).first;
+                c->views.emplace(key, V);
                 grew = true;
             }
-            const BlasView& V = it->second;
+            if (redo) continue;
+            if (!c->layoutOnDevice && (grew || c->geomDirty)) {
+                int rc = upload_vec(c, c->dPairs, c->hPairs.data(), c->hPairs.size() * sizeof(DevPair));
+                if (rc != RZ_OK) return rc;
+                rc = upload_vec(c, c->dTris, c->hTris.data(), c->hTris.size() * sizeof(DevTri));
+                if (rc != RZ_OK) return rc;
+            }
+            break;
+        }
+        c->maxBlasDepth = 1;
+        for (size_t i = 0; i < nInst; ++i) {
+            const BlasView& V = c->views.at(std::make_tuple(inst[i].blasNodeOffset, inst[i].blasTriOffset, inst[i].globalTriOffset));
             DevInstance& D = dev[i];
             std::memset(&D, 0, sizeof D);
             for (int col = 0; col < 4; ++col)
@@ -369,12 +467,6 @@ int finalize_body(rz_ctx* c) {
             D.flags = V.empty ? 1 : 0;
         }
         for (auto& kv : c->views) c->maxBlasDepth = std::max(c->maxBlasDepth, kv.second.depth);
-        if (grew || c->geomDirty) {
-            int rc = upload_vec(c, c->dPairs, c->hPairs.data(), c->hPairs.size() * sizeof(DevPair));
-            if (rc != RZ_OK) return rc;
-            rc = upload_vec(c, c->dTris, c->hTris.data(), c->hTris.size() * sizeof(DevTri));
-            if (rc != RZ_OK) return rc;
-        }
         int rc = upload_vec(c, c->dInst, dev.data(), dev.size() * sizeof(DevInstance));
         if (rc != RZ_OK) return rc;
         // the staging vector dies at scope exit: the copy must have left it
@@ -404,10 +496,6 @@ int finalize_body(rz_ctx* c) {
         rc = upload_vec(c, c->dTlasIdx, ti, nTi * sizeof(int32_t));
         if (rc != RZ_OK) return rc;
     }
-    if (c->matDirty) {
-        int rc = upload_vec(c, c->dMat, c->host[RZ_BIND_MATERIALS].data(), c->host[RZ_BIND_MATERIALS].size());
-        if (rc != RZ_OK) return rc;
-    }
     if (c->lightDirty) {
         int rc = upload_vec(c, c->dLight, c->host[RZ_BIND_LIGHTS].data(), c->host[RZ_BIND_LIGHTS].size());
         if (rc != RZ_OK) return rc;
@@ -417,10 +505,24 @@ int finalize_body(rz_ctx* c) {
         const int nMat = (int)hostCount<rz_material>(c, RZ_BIND_MATERIALS);
         const rz_material* mats = hostArr<rz_material>(c, RZ_BIND_MATERIALS);
         bool transparent = false;
-        for (const DevTri& t : c->hTris) {
-            if (t.mat < 0 || t.mat >= nMat)
-                return fail(c, RZ_ERR_BAD_SCENE, "triangle %d has materialIndex %d, %d materials uploaded", t.src, t.mat, nMat);
-            transparent = transparent || (mats[t.mat].transparency > 0.0f) || !(mats[t.mat].transparency == mats[t.mat].transparency);
+        if (c->layoutOnDevice) {
+            // the gather of rz_relayout.hip checked the triangles it laid out against the materials uploaded above; when
+            // only the materials changed, every laid-out triangle is checked again on the device
+            if (c->matDirty && !c->geomDirty) {
+                unsigned tr = 0; int detail = 0;
+                const int rc = relayout_check_materials_device(static_cast<const DevTri*>(c->dTris.p), c->devTrisUsed, static_cast<const rz_material*>(c->dMat.p),
+                                                               nMat, c->dRelayoutWs.p, c->relayoutPinned, &tr, &detail, c->stream);
+                if (rc < 0) return fail(c, RZ_ERR_HIP, "material check: %s", hipGetErrorString((hipError_t)(-rc)));
+                if (rc > 0) return fail(c, RZ_ERR_BAD_SCENE, "triangle %d has a materialIndex outside the %d materials uploaded", detail, nMat);
+                c->devTransparent = tr;
+            }
+            transparent = c->devTransparent != 0;
+        } else {
+            for (const DevTri& t : c->hTris) {
+                if (t.mat < 0 || t.mat >= nMat)
+                    return fail(c, RZ_ERR_BAD_SCENE, "triangle %d has materialIndex %d, %d materials uploaded", t.src, t.mat, nMat);
+                transparent = transparent || (mats[t.mat].transparency > 0.0f) || !(mats[t.mat].transparency == mats[t.mat].transparency);
+            }
         }
         c->sceneHasTransparency = transparent;
     }
@@ -705,10 +807,11 @@ void rz_destroy(rz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
-                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs})
+                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs, &c->dRawNodes, &c->dRawIdx, &c->dRawTris, &c->dRelayoutWs})
         b->release();
     if (c->wfHostCount) (void)hipHostFree(c->wfHostCount);
     if (c->tlasHostCounts) (void)hipHostFree(c->tlasHostCounts);
+    if (c->relayoutPinned) (void)hipHostFree(c->relayoutPinned);
     for (int i = 0; i < rz_ctx::kRing; ++i) {
         if (c->evStart[i]) (void)hipEventDestroy(c->evStart[i]);
         if (c->evStop[i]) (void)hipEventDestroy(c->evStop[i]);
@@ -1108,6 +1211,28 @@ int rz_read_accum(rz_ctx* c, float* rgba, size_t bytes) {
 }
 int rz_clear_accum(rz_ctx* c) {
     return guarded(c, "rz_clear_accum", [&] { return clear_accum_impl(c); });
+}
+
+int rz_debug_read_layout(rz_ctx* c, int which, void* out, size_t bytes, size_t* needed) {
+    return guarded(c, "rz_debug_read_layout", [&]() -> int {
+        if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+        if (which != 0 && which != 1) return fail(c, RZ_ERR_INVALID_ARG, "which = %d", which);
+        RZ_HIP(c, hipSetDevice(c->device));
+        int rc = finalize(c);
+        if (rc != RZ_OK) return rc;
+        size_t have;
+        const void* src;
+        if (which == 0) { have = (c->layoutOnDevice ? (size_t)c->devPairsUsed : c->hPairs.size()) * sizeof(DevPair); src = c->dPairs.p; }
+        else { have = (c->layoutOnDevice ? (size_t)c->devTrisUsed : c->hTris.size()) * sizeof(DevTri); src = c->dTris.p; }
+        if (needed) *needed = have;
+        if (!out) return RZ_OK;
+        if (bytes < have) return fail(c, RZ_ERR_BUFFER_SIZE, "layout %d holds %zu bytes, buffer has %zu", which, have, bytes);
+        if (have) {
+            RZ_HIP(c, hipMemcpyAsync(out, src, have, hipMemcpyDeviceToHost, c->stream));
+            RZ_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        return RZ_OK;
+    });
 }
 
 int rz_debug_fail_alloc(rz_ctx* c, int nth) {

@@ -169,6 +169,15 @@ class Renderer:
         """Test hook: the nth host allocation site reached from now on throws std::bad_alloc inside the library."""
         self._check(self._L.rz_debug_fail_alloc(self._c, int(nth)), "rz_debug_fail_alloc")
 
+    def debug_read_layout(self, which):
+        """Test hook: the device scene layout as raw bytes (0: DevPair[], 1: DevTri[])."""
+        need = C.c_size_t(0)
+        self._check(self._L.rz_debug_read_layout(self._c, int(which), None, 0, C.byref(need)), "rz_debug_read_layout")
+        out = np.zeros(need.value, np.uint8)
+        self._check(self._L.rz_debug_read_layout(self._c, int(which), out.ctypes.data if need.value else None, out.nbytes, C.byref(need)),
+                    "rz_debug_read_layout")
+        return out
+
     def accum_device_ptr(self):
         return self._L.rz_accum_device_ptr(self._c)
 
