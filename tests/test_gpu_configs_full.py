@@ -129,21 +129,24 @@ def test_bad_alloc_inside_the_library_becomes_a_status_code():
     from rayzen_amd.renderer import RayZenError, Renderer, frame_params
     from helpers import oracle_render
     sc = S.bunny_scene(n=6, extras=True)
-    r = Renderer(0)
-    r.debug_fail_alloc(1)
-    with pytest.raises(RayZenError) as e:
-        r.upload(S.BIND_TRIANGLES, sc.arrays[S.BIND_TRIANGLES])
-    assert e.value.code == -8
-    r.upload_scene(sc)
-    r.set_frame(frame_params(sc.camera, 40, 24, len(sc.lights), 3, 2))
-    for nth in (1, 2, 5, 40):                                   # different depths of the re-layout
-        r.debug_fail_alloc(nth)
-        with pytest.raises(RayZenError) as e:
-            r.render()
-        assert e.value.code == -8, e.value
-    r.debug_fail_alloc(0)
-    r.render()
-    got = r.read_accum()
-    r.close()
     ref = oracle_render(sc, 40, 24, 2, 3)
-    assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+    # flags 0: the scene is re-laid-out on the device (one host staging vector); 4 = RZ_FLAG_HOST_RELAYOUT: the host
+    # re-layout with its growing vectors -- different depths of the same guard
+    for flags, depths in ((0, (1,)), (4, (1, 2, 5, 40))):
+        r = Renderer(0, flags)
+        r.debug_fail_alloc(1)
+        with pytest.raises(RayZenError) as e:
+            r.upload(S.BIND_TRIANGLES, sc.arrays[S.BIND_TRIANGLES])
+        assert e.value.code == -8
+        r.upload_scene(sc)
+        r.set_frame(frame_params(sc.camera, 40, 24, len(sc.lights), 3, 2))
+        for nth in depths:
+            r.debug_fail_alloc(nth)
+            with pytest.raises(RayZenError) as e:
+                r.render()
+            assert e.value.code == -8, e.value
+        r.debug_fail_alloc(0)
+        r.render()
+        got = r.read_accum()
+        r.close()
+        assert (got.view(np.uint32) == ref.view(np.uint32)).all()
