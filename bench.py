@@ -52,6 +52,7 @@ def parse():
                     help="fix the frame's samples per pixel whatever N is (strong scaling; 256 at N = 8 is configs[2])")
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--mesh-n", type=int, default=76, help="bunny stand-in has 12*n*n triangles")
+    ap.add_argument("--obj", default=None, help="render this OBJ instead of the procedural stand-in (default: assets/bunny.obj if present)")
     ap.add_argument("--backend", choices=["auto", "pixel", "wavefront"], default="auto",
                     help="render pipeline: auto = the library's default")
     ap.add_argument("--reduce", choices=["group", "torch", "torch-gloo"], default="group",
@@ -101,7 +102,9 @@ def main():
     W, H, bounces = a.width, a.height, a.bounces
     spp_total = a.spp_total if a.spp_total > 0 else a.spp * world   # every rank renders ALL samples of its own pixels
     scaling = "strong" if a.spp_total > 0 else "weak"
-    sc = S.bunny_scene(n=a.mesh_n, aspect=W / H)
+    # a real bunny.obj dropped into assets/ replaces the procedural stand-in; none ships with the repo
+    obj = a.obj or (os.path.join(ROOT, "assets", "bunny.obj") if os.path.exists(os.path.join(ROOT, "assets", "bunny.obj")) else None)
+    sc = S.bunny_scene(n=a.mesh_n, aspect=W / H, obj_path=obj)
     flags = {"auto": 0, "pixel": 1, "wavefront": 2}[a.backend]
     fp = frame_params(sc.camera, W, H, len(sc.lights), bounces, spp_total, 0, rank, world)
 
@@ -205,7 +208,7 @@ def main():
         "metric": "Msamples/s (rays x spp / s) at 1080p", "value": round(value, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[{2 if (world == 8 and spp_total == 256) else 1}]: bunny stand-in ({sc.name}, {ntri} tris incl. "
+        "config": {"workload": f"configs[{2 if (world == 8 and spp_total == 256) else 1}]: {'OBJ mesh ' + os.path.basename(obj) if obj else 'bunny stand-in'} ({sc.name}, {ntri} tris incl. "
                                f"floor) {W}x{H}, {spp_total} spp per frame ({spp_total // world if scaling == 'strong' else a.spp} "
                                f"spp-equivalents of work per GPU), {bounces} bounces, 2 lights",
                    "width": W, "height": H, "spp_per_gpu": a.spp, "spp_total": spp_total, "bounces": bounces, "triangles": ntri,
@@ -250,7 +253,7 @@ def main():
         if world == 1 and os.path.exists(PMC_JSON):
             try:
                 pj = json.load(open(PMC_JSON))
-                same = pj.get("_source_hash") == src_hash and pj.get("_workload") == [W, H, a.spp, bounces, a.mesh_n]
+                same = pj.get("_source_hash") == src_hash and pj.get("_workload") == [W, H, a.spp, bounces, a.mesh_n] and not obj
                 if same:
                     insts = sum(pj[k] for k in INST_COUNTERS)
                     ach = insts / kernel_s / 1e9

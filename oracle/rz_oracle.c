@@ -116,6 +116,25 @@ static inline int hit_triangle(const rzo_triangle* tri, v3 o, v3 d, float* tHit,
     return 0;
 }
 
+/* ---- optional analysis hook (tests/analysis/late_bounce_model.py): per camera path, the cost of each of its
+ * closest-hit queries in call order (0 primary, 1.. shadow queries, then the bounces), in units of
+ * (BLAS nodes popped)/2 + 2 x (triangles tested) + 3.  Off unless rzo_set_trace_recorder() was given a buffer. */
+#define RZO_REC_CALLS 8
+static uint16_t* g_rec = NULL; static int g_rec_w = 0, g_rec_h = 0, g_rec_spp = 0;
+static __thread uint16_t* t_rec = NULL; static __thread int t_rec_call = 0;
+void rzo_set_trace_recorder(uint16_t* buf, int width, int height, int spp) { g_rec = buf; g_rec_w = width; g_rec_h = height; g_rec_spp = spp; }
+static inline void rec_sample(int x, int y, int s) {
+    t_rec = NULL;
+    if (g_rec && x >= 0 && y >= 0 && x < g_rec_w && y < g_rec_h && s >= 0 && s < g_rec_spp) {
+        t_rec = g_rec + (((size_t)y * g_rec_w + x) * g_rec_spp + s) * RZO_REC_CALLS;
+        t_rec_call = 0;
+    }
+}
+static inline void rec_trace_impl(uint64_t dn, uint64_t dt) {
+    if (t_rec && t_rec_call < RZO_REC_CALLS) { uint64_t v = dn / 2 + 2 * dt + 3; t_rec[t_rec_call++] = (uint16_t)(v > 65535 ? 65535 : v); }
+}
+#define rec_trace(c, n0, t0) rec_trace_impl((c)->cnt.blas_nodes - (n0), (c)->cnt.triangles - (t0))
+
 /* FS:419-454 */
 static int traverse_blas(rctx* c, v3 o, v3 d, int nodeOff, int triOff, int gTriOff,
                          float* tHitOut, v3* hpOut, v3* nOut, int* matOut) {
@@ -161,6 +180,7 @@ static int traverse_tlas(rctx* c, v3 o, v3 d, float* tHitOut, v3* hpOut, v3* nOu
     float tHit = 1e30f;
     int hit = 0;
     c->cnt.traversals++;
+    const uint64_t rec_n0 = c->cnt.blas_nodes, rec_t0 = c->cnt.triangles;
     if (sc->n_tlas_nodes == 0) { *tHitOut = tHit; return 0; }
     int stack[64];
     int sp = 0;
@@ -202,6 +222,7 @@ static int traverse_tlas(rctx* c, v3 o, v3 d, float* tHitOut, v3* hpOut, v3* nOu
             stack[sp++] = node->leftFirst + 1;
         }
     }
+    rec_trace(c, rec_n0, rec_t0);
     *tHitOut = tHit;
     return hit;
 }
@@ -377,6 +398,7 @@ static void shade_pixel(rctx* c, const rzo_frame* fr, int px, int py, float* acc
     float currentIor = *ior;
     for (int samp = fr->sample_base; samp < fr->sample_base + fr->spp; ++samp) {
         c->cnt.samples++;
+        rec_sample(px, py, samp - fr->sample_base);
         float sf = ((fragx + fragy) + (float)samp) + 1.0f;
         v2 seed = {uv.x * sf, uv.y * sf};
         v3 currentOrigin, currentDirection;

@@ -77,6 +77,10 @@ int rzo_render(const rzo_scene* scene, const rzo_frame* frame, float* accum, flo
 /* How many of the last rzo_render call's threads rendered at least one pixel (work is handed out in 16-pixel chunks). */
 int rzo_last_threads_busy(void);
 
+/* Analysis hook: record, for every camera path of later rzo_render calls, the cost of each of its closest-hit queries
+ * (8 uint16 per path: width*height*spp*8 entries, zero-filled by the caller).  NULL switches it off. */
+void rzo_set_trace_recorder(uint16_t* buf, int width, int height, int spp);
+
 /* One closest-hit query (FS:457-503), for known-answer tests.
  * out = {hit(0/1), t, px,py,pz, nx,ny,nz, materialIndex, instanceIdx}. */
 int rzo_trace(const rzo_scene* scene, const float origin[3], const float dir[3], float out[10]);

@@ -305,13 +305,34 @@ def cornell_scene():
     return s.build()
 
 
-def bunny_scene(n=76, aspect=16.0 / 9.0, bunny_material=0, floor_material=4, extras=False, radius=2.8, blas_builder=None):
-    """C2/C3: ~69k-triangle closed mesh ('bunny' stand-in, 12*n*n triangles) over the reference's floor.
+def fit_mesh(tris, radius):
+    """Centre an OBJ mesh on the origin and scale its VERTICES so that its largest half-extent is `radius`.  The scale
+    has to go into the vertices, not the instance transform: the shader's determinant cull |a| < 1e-4 (FS:396) works in
+    object space, and a raw Stanford bunny (0.15 units across) would be culled triangle by triangle."""
+    t = tris.copy()
+    v = np.stack([t["v0"], t["v1"], t["v2"]], axis=1).reshape(-1, 3)
+    lo, hi = v.min(axis=0), v.max(axis=0)
+    centre = ((lo + hi) * np.float32(0.5)).astype(np.float32)
+    k = np.float32(radius) / np.float32(max(float((hi - lo).max()) * 0.5, 1e-20))
+    for f in ("v0", "v1", "v2"):
+        t[f] = ((t[f] - centre) * k).astype(np.float32)
+    return t
+
+
+def bunny_scene(n=76, aspect=16.0 / 9.0, bunny_material=0, floor_material=4, extras=False, radius=2.8, blas_builder=None,
+                obj_path=None):
+    """C2/C3: ~69k-triangle closed mesh over the reference's floor: the procedural 'bunny' stand-in (12*n*n triangles)
+    or, with obj_path, a real OBJ (e.g. the Stanford bunny dropped into assets/bunny.obj) read
+    with RayZen's loader quirks (Mesh.cpp:6-50) and fitted to the same radius.
 
     extras adds a glass blob and a mirror cube so every material branch is exercised."""
     s = Scene(camera=Camera(position=(0.0, 2.5, 10.0), aspect=aspect))
     floor = s.add_mesh(make_cube(floor_material))
-    bunny = s.add_mesh(make_blob(n, radius, bunny_material))
+    if obj_path:
+        mesh = fit_mesh(load_obj(obj_path, bunny_material), radius)
+    else:
+        mesh = make_blob(n, radius, bunny_material)
+    bunny = s.add_mesh(mesh)
     # main.cpp:378: translate(scale(I, (8, .5, 8)), (0, -3, 0))
     s.add_object(floor, translate(scale(identity(), (8.0, 0.5, 8.0)), (0.0, -3.0, 0.0)))
     s.add_object(bunny, translate(identity(), (0.0, 2.0, 0.0)))
@@ -320,7 +341,7 @@ def bunny_scene(n=76, aspect=16.0 / 9.0, bunny_material=0, floor_material=4, ext
         mirror = s.add_mesh(make_cube(2))
         s.add_object(glass, translate(identity(), (4.5, 0.6, 3.0)))
         s.add_object(mirror, rotate(translate(identity(), (-5.0, 0.0, 1.5)), 0.5, (0.0, 1.0, 0.0)))
-    s.name = f"bunny{12 * n * n}" + ("+glass+mirror" if extras else "")
+    s.name = (f"obj:{len(mesh)}" if obj_path else f"bunny{12 * n * n}") + ("+glass+mirror" if extras else "")
     s.set_blas_builder(blas_builder)        # a Renderer: BLAS built on the device (same bytes); None: host builder
     return s.build()
 

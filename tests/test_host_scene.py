@@ -292,3 +292,17 @@ def test_disk_cache_invalidation_and_the_reference_s_stale_data_quirks(tmp_path)
     assert healed.cache_report == dict(ssbo_loaded=False, ssbo_invalidated=False, blas_loaded=4, blas_built=1, tlas_loaded=False)
     for b in S.GEOMETRY_BINDINGS:
         assert healed.arrays[b].tobytes() == want.arrays[b].tobytes(), b
+
+
+def test_obj_mesh_replaces_the_stand_in_and_is_fitted_in_object_space(reference_dir):
+    """a real OBJ dropped into assets/ is rendered instead of the procedural mesh.  Its vertices (not its
+    transform) are scaled: the shader's |a| < 1e-4 cull works in object space (FS:396)."""
+    path = os.path.join(reference_dir, "meshes", "monkey.obj")
+    sc = S.bunny_scene(obj_path=path, radius=2.8)
+    tris = sc.arrays[S.BIND_TRIANGLES]
+    assert len(tris) == 12 + 968                                        # floor cube + Suzanne
+    v = np.stack([tris["v0"][12:], tris["v1"][12:], tris["v2"][12:]]).reshape(-1, 3)
+    half = (v.max(axis=0) - v.min(axis=0)) * 0.5
+    assert abs(float(half.max()) - 2.8) < 1e-4 and np.allclose((v.max(axis=0) + v.min(axis=0)) * 0.5, 0, atol=1e-5)
+    inst = sc.arrays[S.BIND_INSTANCES]
+    assert np.allclose(inst["transform"][1].reshape(4, 4).T[:3, :3], np.eye(3))   # translation only: no scale in the transform
