@@ -172,8 +172,11 @@ int rz_update(rz_ctx* ctx, rz_binding binding, size_t offset,
 /* updateDynamicBVHAndSSBOs (main.cpp:1138-1194) done ON THE DEVICE: hand over only the per-instance transforms
  * (n x 16 floats, column-major, n == number of uploaded instances); the library inverts them, recomputes the world
  * AABBs (main.cpp:1168-1191) and rebuilds the TLAS (BVH.cpp:178-240) in one small kernel.  The result is byte-identical
- * to what RayZen's CPU code would upload with glBufferSubData; rz_read_binding returns it.  Synchronises the context's
- * stream (the TLAS depth sizes the next launch). */
+ * to what the host library (SceneBuffers::updateDynamic, librayzen_host.so) produces and rz_read_binding returns it.
+ * Against a real RayZen build the TLAS topology is the same algorithm, but inverses and world boxes may differ by ulps:
+ * RayZen computes them with GLM (glm::inverse, mat4 * vec4), whose evaluation order is not reproduced here (GLM is not
+ * vendored with the reference).  Synchronises the context's stream (the TLAS depth sizes the next
+ * launch). */
 int rz_update_transforms(rz_ctx* ctx, const float* transforms, size_t n);
 
 /* BVH::buildBLAS (RayZen/src/BVH.cpp:99-175 with the full-sweep SAH of :22-97; called per mesh from main.cpp:954-958)
