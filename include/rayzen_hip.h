@@ -186,6 +186,25 @@ int rz_update_transforms(rz_ctx* ctx, const float* transforms, size_t n);
 int rz_build_blas(rz_ctx* ctx, const rz_triangle* tris, size_t n, rz_bvh_node* nodes_out, size_t nodes_cap,
                   int32_t* indices_out, size_t* n_nodes, int* depth, float* device_ms);
 
+/* initializeSSBOs' geometry half (main.cpp:951-972, 1030-1035) without the host in the middle: builds the BLAS of every
+ * mesh on the device (the builder of rz_build_blas), concatenates nodes and indices THERE, and makes the results the
+ * context's bindings 0, 7 and 8 -- equivalent to BVH::buildBLAS per mesh + rz_upload of the three concatenated arrays,
+ * same bytes, but the node / index arrays never visit the host (rz_read_binding fetches them if asked; at 1 M triangles
+ * the round trip was 28 of rz_build_blas's 36 ms).  `triangles` holds all meshes' triangles back to back; mesh i is
+ * triangles[first_triangle .. +n_triangles).  Per mesh the call returns what an instance of it needs: blasNodeOffset,
+ * blasTriOffset (globalTriOffset is first_triangle) and the BLAS root node, whose box main.cpp:974-993 turns into the
+ * instance's world box for the TLAS.  The frontend then uploads instances, TLAS, materials and lights as usual. */
+typedef struct rz_mesh_build {
+    size_t  first_triangle;  /* in  */
+    size_t  n_triangles;     /* in  */
+    int32_t node_offset;     /* out: blasNodeOffset */
+    int32_t index_offset;    /* out: blasTriOffset  */
+    int32_t n_nodes;         /* out */
+    int32_t depth;           /* out */
+    rz_bvh_node root;        /* out */
+} rz_mesh_build;
+int rz_build_geometry(rz_ctx* ctx, const rz_triangle* triangles, size_t n_triangles, rz_mesh_build* meshes, size_t n_meshes);
+
 /* Copy a binding's current content back to the host in RayZen's own layout (after rz_update_transforms: the
  * instances / TLAS nodes / TLAS indices the device built).  out == NULL: only *needed is set. */
 int rz_read_binding(rz_ctx* ctx, rz_binding binding, void* out, size_t bytes, size_t* needed);

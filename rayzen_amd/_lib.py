@@ -12,7 +12,7 @@ HOST_SO = os.path.join(_HERE, "lib", "librayzen_host.so")
 
 # the symbols include/rayzen_hip.h declares
 HIP_SYMBOLS = (
-    "rz_create", "rz_destroy", "rz_last_error", "rz_upload", "rz_update", "rz_update_transforms", "rz_build_blas", "rz_read_binding",
+    "rz_create", "rz_destroy", "rz_last_error", "rz_upload", "rz_update", "rz_update_transforms", "rz_build_blas", "rz_build_geometry", "rz_read_binding",
     "rz_set_frame", "rz_set_stream",
     "rz_bind_accum", "rz_render", "rz_render_counted", "rz_sync", "rz_clear_accum", "rz_read_accum",
     "rz_resolve_rgba8", "rz_present", "rz_last_render_ms", "rz_render_history_ms", "rz_last_kernel_name", "rz_accum_device_ptr", "rz_version", "rz_sizeof",
@@ -54,6 +54,17 @@ class PresentParams(C.Structure):
                 ("bvh_mode", C.c_int32), ("selected_blas", C.c_int32), ("selected_tri", C.c_int32)]
 
 
+class BvhNode(C.Structure):
+    """rz_bvh_node of include/rayzen_hip.h."""
+    _fields_ = [("boundsMin", C.c_float * 3), ("leftFirst", C.c_int32), ("boundsMax", C.c_float * 3), ("count", C.c_int32)]
+
+
+class MeshBuild(C.Structure):
+    """rz_mesh_build of include/rayzen_hip.h."""
+    _fields_ = [("first_triangle", C.c_size_t), ("n_triangles", C.c_size_t), ("node_offset", C.c_int32),
+                ("index_offset", C.c_int32), ("n_nodes", C.c_int32), ("depth", C.c_int32), ("root", BvhNode)]
+
+
 class Counters(C.Structure):
     """rz_counters of include/rayzen_hip.h."""
     _fields_ = [(n, C.c_uint64) for n in COUNTER_FIELDS]
@@ -80,6 +91,7 @@ def hip():
         L.rz_update_transforms.restype, L.rz_update_transforms.argtypes = i, [vp, vp, sz]
         L.rz_read_binding.restype, L.rz_read_binding.argtypes = i, [vp, i, vp, sz, C.POINTER(sz)]
         L.rz_build_blas.restype, L.rz_build_blas.argtypes = i, [vp, vp, sz, vp, sz, vp, C.POINTER(sz), C.POINTER(C.c_int), C.POINTER(C.c_float)]
+        L.rz_build_geometry.restype, L.rz_build_geometry.argtypes = i, [vp, vp, sz, C.POINTER(MeshBuild), sz]
         L.rz_set_frame.restype, L.rz_set_frame.argtypes = i, [vp, C.POINTER(FrameParams)]
         L.rz_set_stream.restype, L.rz_set_stream.argtypes = i, [vp, vp]
         L.rz_bind_accum.restype, L.rz_bind_accum.argtypes = i, [vp, vp, sz]

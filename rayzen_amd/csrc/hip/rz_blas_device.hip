@@ -887,8 +887,8 @@ size_t blas_build_workspace_bytes(size_t n) {
 
 #define BB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { if (temp) (void)hipFree(temp); return (int)e_; } } while (0)
 
-// Returns 0, a hipError_t (> 0), or -1 (bad arguments / internal limit).  nodes_out (capacity 2n+1) and idx_out (n)
-// are HOST pointers.  ms (optional): device time from the first kernel to the last, copies excluded.
+// Returns 0, a hipError_t (> 0), or -1 (bad arguments / internal limit).  hostTris, nodes_out (capacity 2n+1) and
+// idx_out (n) may be HOST or DEVICE pointers (copies use hipMemcpyDefault).  ms (optional): device time from the first kernel to the last, copies excluded.
 int blas_build_device(const rz_triangle* hostTris, size_t n, void* workspace, size_t workspaceBytes, rz_bvh_node* nodes_out,
                       int32_t* idx_out, int* nNodesOut, int* depthOut, float* ms, hipStream_t s) {
     void* temp = nullptr;
@@ -928,7 +928,7 @@ int blas_build_device(const rz_triangle* hostTris, size_t n, void* workspace, si
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ms) { BB_HIP(hipEventCreate(&ev0)); BB_HIP(hipEventCreate(&ev1)); }
-    BB_HIP(hipMemcpyAsync(devTris, hostTris, N * sizeof(rz_triangle), hipMemcpyHostToDevice, s));
+    BB_HIP(hipMemcpyAsync(devTris, hostTris, N * sizeof(rz_triangle), hipMemcpyDefault, s));
     if (ms) BB_HIP(hipEventRecord(ev0, s));
     const int blocks = (int)((N + 255) / 256);
     hipLaunchKernelGGL(bb_prepare, dim3(blocks), dim3(256), 0, s, B);
@@ -974,8 +974,8 @@ int blas_build_device(const rz_triangle* hostTris, size_t n, void* workspace, si
     hipLaunchKernelGGL(bb_emit, dim3(nb), dim3(256), 0, s, B, refIdx, nNodes);
     BB_HIP(hipGetLastError());
     if (ms) BB_HIP(hipEventRecord(ev1, s));
-    BB_HIP(hipMemcpyAsync(nodes_out, B.outNodes, (size_t)nNodes * sizeof(rz_bvh_node), hipMemcpyDeviceToHost, s));
-    BB_HIP(hipMemcpyAsync(idx_out, B.idx, N * 4, hipMemcpyDeviceToHost, s));
+    BB_HIP(hipMemcpyAsync(nodes_out, B.outNodes, (size_t)nNodes * sizeof(rz_bvh_node), hipMemcpyDefault, s));
+    BB_HIP(hipMemcpyAsync(idx_out, B.idx, N * 4, hipMemcpyDefault, s));
     BB_HIP(hipStreamSynchronize(s));
     if (ms) { BB_HIP(hipEventElapsedTime(ms, ev0, ev1)); (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
     (void)hipFree(temp);

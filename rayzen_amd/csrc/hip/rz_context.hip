@@ -156,6 +156,10 @@ struct rz_ctx {
     bool layoutOnDevice = false;        // dPairs / dTris were produced on the device (hPairs / hTris are empty)
     long long devPairsUsed = 0, devTrisUsed = 0;
     unsigned devTransparent = 0;
+    // rz_build_geometry: BLAS nodes / indices live in dRawNodes / dRawIdx; the host copies are fetched on demand
+    bool geomOnDevice = false, geomHostFresh = false;
+    size_t devNodes = 0, devIdx = 0;
+    std::map<int, rz_bvh_node> devRoots;    // node offset of a mesh -> its root node
 };
 
 namespace {
@@ -217,10 +221,15 @@ int upload_vec(rz_ctx* c, DevBuf& b, const void* src, size_t bytes) {
 
 template <class T> const T* hostArr(const rz_ctx* c, int b) { return reinterpret_cast<const T*>(c->host[b].data()); }
 template <class T> size_t hostCount(const rz_ctx* c, int b) { return c->host[b].size() / sizeof(T); }
+size_t blasNodeCount(const rz_ctx* c) { return c->geomOnDevice ? c->devNodes : hostCount<rz_bvh_node>(c, RZ_BIND_BLAS_NODES); }
+size_t blasIdxCount(const rz_ctx* c) { return c->geomOnDevice ? c->devIdx : hostCount<int32_t>(c, RZ_BIND_BLAS_INDICES); }
+
+int sync_geom_host(rz_ctx* c);
 
 // Lay out one BLAS: breadth-first walk from its root, one DevPair per internal
 // node (so the hot top levels are contiguous), triangles gathered to leaf order.
 int build_view(rz_ctx* c, int nodeOff, int triOff, int gTriOff, BlasView& V) {
+    { int rc = sync_geom_host(c); if (rc != RZ_OK) return rc; }
     const rz_bvh_node* nodes = hostArr<rz_bvh_node>(c, RZ_BIND_BLAS_NODES);
     const int32_t* idx = hostArr<int32_t>(c, RZ_BIND_BLAS_INDICES);
     const rz_triangle* tris = hostArr<rz_triangle>(c, RZ_BIND_TRIANGLES);
@@ -309,6 +318,20 @@ int build_view(rz_ctx* c, int nodeOff, int triOff, int gTriOff, BlasView& V) {
 
 // After rz_update_transforms the device holds newer instances / TLAS than the host copies: bring them back
 // (3.4 KB at 16 instances) before anything reads or patches those copies.
+// After rz_build_geometry the BLAS nodes / indices exist only on the device: bring them to the host copies before
+// anything reads or patches those (rz_read_binding, rz_update, the host re-layout, the wireframe's path walk).
+int sync_geom_host(rz_ctx* c) {
+    if (!c->geomOnDevice || c->geomHostFresh) return RZ_OK;
+    alloc_point(c);
+    c->host[RZ_BIND_BLAS_NODES].resize(c->devNodes * sizeof(rz_bvh_node));
+    c->host[RZ_BIND_BLAS_INDICES].resize(c->devIdx * sizeof(int32_t));
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->devNodes) RZ_HIP(c, hipMemcpy(c->host[RZ_BIND_BLAS_NODES].data(), c->dRawNodes.p, c->devNodes * sizeof(rz_bvh_node), hipMemcpyDeviceToHost));
+    if (c->devIdx) RZ_HIP(c, hipMemcpy(c->host[RZ_BIND_BLAS_INDICES].data(), c->dRawIdx.p, c->devIdx * sizeof(int32_t), hipMemcpyDeviceToHost));
+    c->geomHostFresh = true;
+    return RZ_OK;
+}
+
 int sync_host_from_device(rz_ctx* c) {
     if (!c->deviceOwnsTlas) return RZ_OK;
     const size_t nInst = hostCount<rz_bvh_instance>(c, RZ_BIND_INSTANCES);
@@ -354,11 +377,14 @@ bool host_relayout_forced(const rz_ctx* c) {
 }
 
 int prepare_device_relayout(rz_ctx* c) {       // raw arrays + materials on the device, output buffers sized, scratch
-    const size_t nNodes = hostCount<rz_bvh_node>(c, RZ_BIND_BLAS_NODES), nIdx = hostCount<int32_t>(c, RZ_BIND_BLAS_INDICES);
-    int rc = upload_vec(c, c->dRawNodes, c->host[RZ_BIND_BLAS_NODES].data(), c->host[RZ_BIND_BLAS_NODES].size());
-    if (rc != RZ_OK) return rc;
-    rc = upload_vec(c, c->dRawIdx, c->host[RZ_BIND_BLAS_INDICES].data(), c->host[RZ_BIND_BLAS_INDICES].size());
-    if (rc != RZ_OK) return rc;
+    const size_t nNodes = blasNodeCount(c), nIdx = blasIdxCount(c);
+    int rc;
+    if (!c->geomOnDevice) {                    // (rz_build_geometry left nodes and indices there already)
+        rc = upload_vec(c, c->dRawNodes, c->host[RZ_BIND_BLAS_NODES].data(), c->host[RZ_BIND_BLAS_NODES].size());
+        if (rc != RZ_OK) return rc;
+        rc = upload_vec(c, c->dRawIdx, c->host[RZ_BIND_BLAS_INDICES].data(), c->host[RZ_BIND_BLAS_INDICES].size());
+        if (rc != RZ_OK) return rc;
+    }
     rc = upload_vec(c, c->dRawTris, c->host[RZ_BIND_TRIANGLES].data(), c->host[RZ_BIND_TRIANGLES].size());
     if (rc != RZ_OK) return rc;
     rc = ensure(c, c->dPairs, std::max<size_t>(nNodes, 1) * sizeof(DevPair));
@@ -372,16 +398,24 @@ int prepare_device_relayout(rz_ctx* c) {       // raw arrays + materials on the 
 }
 
 int device_view(rz_ctx* c, int nodeOff, int triOff, int gTriOff, BlasView& V) {
-    const long long nNodes = (long long)hostCount<rz_bvh_node>(c, RZ_BIND_BLAS_NODES);
-    const long long nIdx = (long long)hostCount<int32_t>(c, RZ_BIND_BLAS_INDICES);
+    const long long nNodes = (long long)blasNodeCount(c);
+    const long long nIdx = (long long)blasIdxCount(c);
     const long long nTris = (long long)hostCount<rz_triangle>(c, RZ_BIND_TRIANGLES);
     if (nodeOff < 0 || nodeOff >= nNodes) return 1;
+    rz_bvh_node root;
+    if (c->geomOnDevice) {
+        auto it = c->devRoots.find(nodeOff);
+        if (it == c->devRoots.end()) return 1;      // an instance that does not start at a mesh's root: let the host path look at it
+        root = it->second;
+    } else {
+        root = hostArr<rz_bvh_node>(c, RZ_BIND_BLAS_NODES)[nodeOff];
+    }
     RelayoutView R{};
     R.nodeOff = nodeOff; R.triOff = triOff; R.gTriOff = gTriOff;
     R.pairBase = (int)c->devPairsUsed; R.triBase = (int)c->devTrisUsed;
     const int rc = relayout_view_device(static_cast<const rz_bvh_node*>(c->dRawNodes.p), nNodes, static_cast<const int32_t*>(c->dRawIdx.p), nIdx,
                                         static_cast<const rz_triangle*>(c->dRawTris.p), nTris, static_cast<const rz_material*>(c->dMat.p),
-                                        (int)hostCount<rz_material>(c, RZ_BIND_MATERIALS), hostArr<rz_bvh_node>(c, RZ_BIND_BLAS_NODES)[nodeOff], R,
+                                        (int)hostCount<rz_material>(c, RZ_BIND_MATERIALS), root, R,
                                         static_cast<DevPair*>(c->dPairs.p), (long long)(c->dPairs.cap / sizeof(DevPair)),
                                         static_cast<DevTri*>(c->dTris.p), (long long)(c->dTris.cap / sizeof(DevTri)), c->dRelayoutWs.p,
                                         c->dRelayoutWs.cap, c->relayoutPinned, &c->devTransparent, c->stream);
@@ -827,6 +861,11 @@ static int upload_impl(rz_ctx* c, rz_binding binding, const void* data, size_t b
     if (bytes % es) return fail(c, RZ_ERR_INVALID_ARG, "binding %d: %zu bytes is not a multiple of the %zu-byte element", (int)binding, bytes, es);
     if (bytes && !data) return fail(c, RZ_ERR_INVALID_ARG, "null data");
     if (c->deviceOwnsTlas) { int rc = sync_host_from_device(c); if (rc != RZ_OK) return rc; }
+    if (c->geomOnDevice && (binding == RZ_BIND_BLAS_NODES || binding == RZ_BIND_BLAS_INDICES)) {
+        int rc = sync_geom_host(c);         // the other of the two arrays must survive on the host
+        if (rc != RZ_OK) return rc;
+        c->geomOnDevice = false;
+    }
     alloc_point(c);
     c->host[binding].assign(static_cast<const unsigned char*>(data), static_cast<const unsigned char*>(data) + bytes);
     c->present[binding] = true;
@@ -846,6 +885,11 @@ static int update_impl(rz_ctx* c, rz_binding binding, size_t offset, const void*
     if (!c->present[binding]) return fail(c, RZ_ERR_NOT_READY, "binding %d has not been uploaded", (int)binding);
     if (bytes && !data) return fail(c, RZ_ERR_INVALID_ARG, "null data");
     if (c->deviceOwnsTlas) { int rc = sync_host_from_device(c); if (rc != RZ_OK) return rc; }
+    if (c->geomOnDevice && (binding == RZ_BIND_BLAS_NODES || binding == RZ_BIND_BLAS_INDICES)) {
+        int rc = sync_geom_host(c);
+        if (rc != RZ_OK) return rc;
+        c->geomOnDevice = false;            // the host copies are the truth again
+    }
     if (offset > c->host[binding].size() || bytes > c->host[binding].size() - offset)
         return fail(c, RZ_ERR_OUT_OF_RANGE, "binding %d: update [%zu,+%zu) past its %zu bytes", (int)binding, offset, bytes, c->host[binding].size());
     if (bytes == 0) return RZ_OK;
@@ -911,6 +955,67 @@ static int update_transforms_impl(rz_ctx* c, const float* transforms, size_t n) 
     return RZ_OK;
 }
 
+static int build_geometry_impl(rz_ctx* c, const rz_triangle* triangles, size_t nTris, rz_mesh_build* meshes, size_t nMeshes) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    if ((nTris && !triangles) || (nMeshes && !meshes)) return fail(c, RZ_ERR_INVALID_ARG, "null argument");
+    if (nTris > ((size_t)1 << 30)) return fail(c, RZ_ERR_INVALID_ARG, "too many triangles");
+    size_t capNodes = 0, capIdx = 0, maxN = 0;
+    for (size_t i = 0; i < nMeshes; ++i) {
+        const rz_mesh_build& m = meshes[i];
+        if (m.first_triangle > nTris || m.n_triangles > nTris - m.first_triangle)
+            return fail(c, RZ_ERR_INVALID_ARG, "mesh %zu: triangles [%zu,+%zu) outside the %zu given", i, m.first_triangle, m.n_triangles, nTris);
+        capNodes += m.n_triangles ? 2 * m.n_triangles - 1 : 1;
+        capIdx += m.n_triangles;
+        maxN = std::max(maxN, m.n_triangles);
+    }
+    if (capNodes > ((size_t)1 << 30)) return fail(c, RZ_ERR_INVALID_ARG, "too many nodes");
+    RZ_HIP(c, hipSetDevice(c->device));
+    if (c->deviceOwnsTlas) { int rc = sync_host_from_device(c); if (rc != RZ_OK) return rc; }
+    int rc = ensure(c, c->dRawNodes, std::max<size_t>(capNodes, 1) * sizeof(rz_bvh_node));
+    if (rc != RZ_OK) return rc;
+    rc = ensure(c, c->dRawIdx, std::max<size_t>(capIdx, 1) * sizeof(int32_t));
+    if (rc != RZ_OK) return rc;
+    if (maxN) { rc = ensure(c, c->dBuildWs, blas_build_workspace_bytes(maxN)); if (rc != RZ_OK) return rc; }
+    std::map<int, rz_bvh_node> roots;
+    size_t nodeOff = 0, idxOff = 0;
+    rz_bvh_node* dNodes = static_cast<rz_bvh_node*>(c->dRawNodes.p);
+    int32_t* dIdx = static_cast<int32_t*>(c->dRawIdx.p);
+    for (size_t i = 0; i < nMeshes; ++i) {
+        rz_mesh_build& m = meshes[i];
+        int nn = 1, depth = 1;
+        rz_bvh_node root{};
+        if (m.n_triangles == 0) {       // BVH.cpp:101-118 on an empty mesh: one root with an inverted box and no triangles
+            const float fmax = std::numeric_limits<float>::max();
+            for (int k = 0; k < 3; ++k) { root.boundsMin[k] = fmax; root.boundsMax[k] = -fmax; }
+            root.leftFirst = 0; root.count = 0;
+            RZ_HIP(c, hipMemcpyAsync(dNodes + nodeOff, &root, sizeof root, hipMemcpyHostToDevice, c->stream));
+            RZ_HIP(c, hipStreamSynchronize(c->stream));
+        } else {
+            const int e = blas_build_device(triangles + m.first_triangle, m.n_triangles, c->dBuildWs.p, c->dBuildWs.cap, dNodes + nodeOff,
+                                            dIdx + idxOff, &nn, &depth, nullptr, c->stream);
+            if (e > 0) return fail(c, RZ_ERR_HIP, "device BLAS build of mesh %zu: %s", i, hipGetErrorString((hipError_t)e));
+            if (e < 0) return fail(c, RZ_ERR_HIP, "device BLAS build of mesh %zu: internal limit", i);
+            RZ_HIP(c, hipMemcpy(&root, dNodes + nodeOff, sizeof root, hipMemcpyDeviceToHost));
+        }
+        m.node_offset = (int32_t)nodeOff; m.index_offset = (int32_t)idxOff; m.n_nodes = nn; m.depth = depth; m.root = root;
+        alloc_point(c);
+        roots[(int)nodeOff] = root;
+        nodeOff += (size_t)nn; idxOff += m.n_triangles;
+    }
+    // the three geometry bindings now are: the caller's triangles (host copy, uploaded by the re-layout as usual) and the
+    // device-resident node / index arrays
+    alloc_point(c);
+    c->host[RZ_BIND_TRIANGLES].assign(reinterpret_cast<const unsigned char*>(triangles), reinterpret_cast<const unsigned char*>(triangles) + nTris * sizeof(rz_triangle));
+    c->host[RZ_BIND_BLAS_NODES].clear();
+    c->host[RZ_BIND_BLAS_INDICES].clear();
+    c->present[RZ_BIND_TRIANGLES] = c->present[RZ_BIND_BLAS_NODES] = c->present[RZ_BIND_BLAS_INDICES] = true;
+    c->geomOnDevice = true; c->geomHostFresh = false;
+    c->devNodes = nodeOff; c->devIdx = idxOff;
+    c->devRoots.swap(roots);
+    c->geomDirty = true;
+    return RZ_OK;
+}
+
 static int build_blas_impl(rz_ctx* c, const rz_triangle* tris, size_t n, rz_bvh_node* nodes_out, size_t nodes_cap, int32_t* indices_out,
                   size_t* n_nodes, int* depth, float* device_ms) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
@@ -952,6 +1057,7 @@ static int read_binding_impl(rz_ctx* c, rz_binding binding, void* out, size_t by
     if (elem_size((int)binding) == 0) return fail(c, RZ_ERR_INVALID_ARG, "unknown binding %d", (int)binding);
     if (!c->present[binding]) return fail(c, RZ_ERR_NOT_READY, "binding %d has not been uploaded", (int)binding);
     if (c->deviceOwnsTlas) { int rc = sync_host_from_device(c); if (rc != RZ_OK) return rc; c->deviceOwnsTlas = true; }
+    if (c->geomOnDevice && (binding == RZ_BIND_BLAS_NODES || binding == RZ_BIND_BLAS_INDICES)) { int rc = sync_geom_host(c); if (rc != RZ_OK) return rc; }
     const size_t have = c->host[binding].size();
     if (needed) *needed = have;
     if (!out) return RZ_OK;
@@ -1100,6 +1206,8 @@ static int present_impl(rz_ctx* c, const rz_present_params* pp, uint8_t* rgba8, 
     if (pp->show_bvh && pp->bvh_mode == 1 && pp->selected_blas >= 0 && pp->selected_blas < P.nInstances) {
         // findBVHBranchIterative (glsl:257-307) does not depend on the pixel: walk it once here
         if (c->deviceOwnsTlas) { rc = sync_host_from_device(c); if (rc != RZ_OK) return rc; c->deviceOwnsTlas = true; }
+        rc = sync_geom_host(c);
+        if (rc != RZ_OK) return rc;
         const rz_bvh_instance* inst = hostArr<rz_bvh_instance>(c, RZ_BIND_INSTANCES);
         const rz_bvh_node* nodes = hostArr<rz_bvh_node>(c, RZ_BIND_BLAS_NODES);
         const int32_t* idx = hostArr<int32_t>(c, RZ_BIND_BLAS_INDICES);
@@ -1211,6 +1319,10 @@ int rz_read_accum(rz_ctx* c, float* rgba, size_t bytes) {
 }
 int rz_clear_accum(rz_ctx* c) {
     return guarded(c, "rz_clear_accum", [&] { return clear_accum_impl(c); });
+}
+
+int rz_build_geometry(rz_ctx* c, const rz_triangle* triangles, size_t n_triangles, rz_mesh_build* meshes, size_t n_meshes) {
+    return guarded(c, "rz_build_geometry", [&] { return build_geometry_impl(c, triangles, n_triangles, meshes, n_meshes); });
 }
 
 int rz_debug_read_layout(rz_ctx* c, int which, void* out, size_t bytes, size_t* needed) {

@@ -92,6 +92,56 @@ class Renderer:
                     "rz_build_blas")
         return nodes[:nn.value].copy(), idx, depth.value, ms.value
 
+    def build_geometry(self, triangles, ranges):
+        """rz_build_geometry: triangles = all meshes back to back (TRIANGLE dtype), ranges = [(first, count), ...].
+        Builds every BLAS on the device, leaves nodes / indices there as bindings 7 / 8 (and the triangles as binding 0).
+        Returns one dict per mesh: node_offset, index_offset, n_nodes, depth, root (a BVH_NODE record)."""
+        from .scene import BVH_NODE as NODE_DTYPE, TRIANGLE as TRIANGLE_DTYPE
+        t = np.ascontiguousarray(triangles, TRIANGLE_DTYPE)
+        arr = (_lib.MeshBuild * len(ranges))()
+        for k, (first, count) in enumerate(ranges):
+            arr[k].first_triangle, arr[k].n_triangles = int(first), int(count)
+        self._check(self._L.rz_build_geometry(self._c, t.ctypes.data if t.shape[0] else None, t.shape[0], arr, len(ranges)),
+                    "rz_build_geometry")
+        out = []
+        for m in arr:
+            root = np.zeros(1, NODE_DTYPE)
+            C.memmove(root.ctypes.data, C.addressof(m.root), 32)
+            out.append(dict(node_offset=m.node_offset, index_offset=m.index_offset, n_nodes=m.n_nodes, depth=m.depth, root=root[0]))
+        return out
+
+    def upload_scene_built_on_device(self, meshes, objects, materials, lights):
+        """initializeSSBOs with the geometry half on the device: meshes = list of TRIANGLE arrays, objects = list of
+        (mesh index, 16-float column-major transform).  One BLAS per distinct mesh (true instancing).  Instances, world
+        boxes and the TLAS are assembled with librayzen_host exactly as SceneBuffers::build does; returns the arrays
+        uploaded for bindings 5, 6 and 9 as a dict (nodes / indices stay on the device: read_binding fetches them)."""
+        from . import scene as S
+        ranges, first = [], 0
+        for m in meshes:
+            ranges.append((first, len(m)))
+            first += len(m)
+        tris = np.concatenate([np.ascontiguousarray(m, S.TRIANGLE) for m in meshes]) if meshes else np.zeros(0, S.TRIANGLE)
+        built = self.build_geometry(tris, ranges)
+        inst = np.zeros(len(objects), S.BVH_INSTANCE)
+        roots = np.zeros(len(objects), S.BVH_NODE)
+        for i, (mi, xf) in enumerate(objects):
+            xf = np.ascontiguousarray(xf, np.float32).reshape(16)
+            b = built[mi]
+            inst[i] = (b["node_offset"], b["index_offset"], i, ranges[mi][0], xf, S.inverse(xf))
+            mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)
+            r1 = np.zeros(1, S.BVH_NODE)
+            r1[0] = b["root"]
+            _lib.host().rzh_world_bounds(r1.ctypes.data, xf.ctypes.data, mn.ctypes.data, mx.ctypes.data)
+            roots[i] = b["root"]
+            roots[i]["boundsMin"], roots[i]["boundsMax"] = mn, mx
+        tn, ti = S.build_tlas(roots)
+        self.upload(S.BIND_INSTANCES, inst)
+        self.upload(S.BIND_TLAS_NODES, tn)
+        self.upload(S.BIND_TLAS_INDICES, ti)
+        self.upload(S.BIND_MATERIALS, materials)
+        self.upload(S.BIND_LIGHTS, lights)
+        return {S.BIND_INSTANCES: inst, S.BIND_TLAS_NODES: tn, S.BIND_TLAS_INDICES: ti, S.BIND_TRIANGLES: tris}
+
     def read_binding(self, binding):
         """The binding's current content in RayZen's layout (what the device built, after update_transforms)."""
         need = C.c_size_t(0)

@@ -104,11 +104,14 @@ def test_relayout_time_one_million_triangles():
     sc = S.stress_scene(n=289, blas_builder=r)
     for flags, name in ((0, "device"), (HOST_RELAYOUT, "host")):
         q = Renderer(0, flags)
-        q.upload_scene(sc)
-        q.set_frame(frame_params(sc.camera, 64, 36, len(sc.lights), 2, 1))
-        t = time.perf_counter()
-        q.debug_read_layout(0)
-        dt = time.perf_counter() - t
-        print(f"[relayout] {name}: {dt * 1e3:.1f} ms for {sc.arrays[S.BIND_TRIANGLES].shape[0]} triangles (incl. uploads and one 40 MB read-back)")
+        times = []
+        for _ in range(3):                           # the first pass pays for the allocations
+            q.upload_scene(sc)
+            q.set_frame(frame_params(sc.camera, 64, 36, len(sc.lights), 2, 1))
+            t = time.perf_counter()
+            q.render(); q.sync()                     # upload of the raw arrays + re-layout + one tiny frame
+            times.append(time.perf_counter() - t)
+        print(f"[relayout] {name}: {min(times) * 1e3:.1f} ms to the first frame after an upload of "
+              f"{sc.arrays[S.BIND_TRIANGLES].shape[0]} triangles (best of 3; first {times[0] * 1e3:.1f})")
         q.close()
     r.close()
