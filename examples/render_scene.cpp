@@ -4,10 +4,11 @@
 //
 //   g++ -std=c++17 -O2 -Iinclude -Irayzen_amd/csrc/host examples/render_scene.cpp
 //       -Lrayzen_amd/lib -lrayzen_host -lrayzen_hip -Wl,-rpath,$PWD/rayzen_amd/lib -o render_scene
-//   ./render_scene out.ppm [width height spp frames]
+//   ./render_scene out.ppm [width height spp frames [device]]     (device: BLAS built and kept on the GPU, rz_build_geometry)
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <string>
 
 #include "RayZenScene.h"
 #include "Renderer.h"
@@ -32,6 +33,7 @@ int main(int argc, char** argv) {
     const char* out = argc > 1 ? argv[1] : "out.ppm";
     const int W = argc > 2 ? std::atoi(argv[2]) : 640, H = argc > 3 ? std::atoi(argv[3]) : 360;
     const int spp = argc > 4 ? std::atoi(argv[4]) : 16, frames = argc > 5 ? std::atoi(argv[5]) : 3;
+    const bool onDevice = argc > 6 && std::string(argv[6]) == "device";
 
     Scene scene;
     scene.camera = Camera(vec3(0.0f, 2.5f, 10.0f), vec3(0.0f, 0.0f, -1.0f), vec3(0.0f, 1.0f, 0.0f), 70.0f,
@@ -50,7 +52,8 @@ int main(int argc, char** argv) {
 
     try {
         Renderer renderer(0);
-        renderer.initializeSSBOs(scene);                                   // main.cpp:388
+        if (onDevice) renderer.initializeSSBOsOnDevice(scene);             // the same, geometry half on the GPU
+        else renderer.initializeSSBOs(scene, /*shareMeshes=*/true);        // main.cpp:388
         for (int frame = 0; frame < frames; ++frame) {                     // main.cpp:408 render loop
             scene.gameObjects[2].transform = translate(mat4(1.0f), vec3(4.5f - 0.5f * frame, 0.6f, 3.0f));
             renderer.updateDynamicBVHAndSSBOs(scene);                      // main.cpp:572

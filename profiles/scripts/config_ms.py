@@ -9,7 +9,10 @@ from rayzen_amd.renderer import Renderer, frame_params
 cfgs = {"c2": lambda: (S.bunny_scene(n=76, aspect=16 / 9), 1920, 1080, 64, 4),
         "c2g": lambda: (S.bunny_scene(n=76, aspect=16 / 9, extras=True), 1920, 1080, 64, 4),
         "c4": lambda: (S.instanced_scene(n=76, count=16, aspect=16 / 9), 1920, 1080, 16, 4),
-        "c5": lambda: (S.stress_scene(n=289, aspect=16 / 9), 3840, 2160, 32, 8)}
+        "c5": lambda: (S.stress_scene(n=289, aspect=16 / 9), 3840, 2160, 32, 8),
+        "c5full": lambda: (S.stress_scene(n=289, aspect=16 / 9), 3840, 2160, 128, 8),
+        "c3": lambda: (S.bunny_scene(n=76, aspect=16 / 9), 1920, 1080, 256, 4),
+        "mirror": lambda: (S.bunny_scene(n=76, aspect=16 / 9, bunny_material=2, floor_material=2), 1920, 1080, 64, 8)}
 out = []
 for name in (sys.argv[1:] or ["c2", "c4", "c5"]):
     sc, W, H, spp, b = cfgs[name]()

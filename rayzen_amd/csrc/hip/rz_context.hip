@@ -40,8 +40,8 @@ int blas_build_device(const rz_triangle* hostTris, size_t n, void* workspace, si
 void dump_wave_log(int nWaves);
 #endif
 void launch_render_pixels(const KParams& K, bool counted, hipStream_t stream);
-SamplesPlan plan_render_samples(int spp, int nSlots);
-size_t samples_lds_extra(bool glass);
+SamplesPlan plan_render_samples(int spp, int nSlots, bool glass);
+size_t samples_lds_extra(bool glass, bool compact);
 void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream_t stream);
 void launch_resolve(const float4* accum, uchar4* out, int n, hipStream_t stream);
 struct RelayoutView {        // rz_relayout.hip
@@ -151,7 +151,7 @@ struct rz_ctx {
     size_t extAccumBytes = 0;
     int failAllocCountdown = 0;         // rz_debug_fail_alloc (test hook)
     // device re-layout (rz_relayout.hip): the caller's raw arrays on the device, the fill of dPairs / dTris, scratch
-    DevBuf dRawNodes, dRawIdx, dRawTris, dRelayoutWs;
+    DevBuf dRawNodes, dRawIdx, dRawTris, dRelayoutWs, dClaimScratch;
     int* relayoutPinned = nullptr;
     bool layoutOnDevice = false;        // dPairs / dTris were produced on the device (hPairs / hTris are empty)
     long long devPairsUsed = 0, devTrisUsed = 0;
@@ -578,6 +578,10 @@ int finalize(rz_ctx* c) {
     }
 }
 
+#ifndef RZ_CLAIM_STRIDE_PAD
+#define RZ_CLAIM_STRIDE_PAD 0      // extra dwords between the scratch regions of neighbouring resident waves
+#endif
+
 constexpr int kWfMaxRounds = 16384;
 
 bool use_wavefront(const rz_ctx* c, const KParams& K) {
@@ -660,7 +664,7 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     // opaque variant = its VGPR limit, and for the transparent one too: 5.4 KB of versions leave it a 9-entry window --
     // measured 40.2 -> 34.3 ms on the glass+mirror scene against 12 waves with the whole stack in LDS); deeper entries go to global overflow columns,
     // which are indexed by resident workgroup and therefore only exist for persistent launches.
-    const SamplesPlan plan = plan_render_samples(K.spp, K.nSlots);
+    const SamplesPlan plan = plan_render_samples(K.spp, K.nSlots, c->sceneHasTransparency);
     const int need = K.blasStackCap;
 #ifndef RZ_GLASS_WAVES_PER_CU
 #define RZ_GLASS_WAVES_PER_CU 16
@@ -669,7 +673,7 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
 #define RZ_OPAQUE_WAVES_PER_CU 16
 #endif
     const size_t budget = (size_t)160 * 1024 / (c->sceneHasTransparency ? RZ_GLASS_WAVES_PER_CU : RZ_OPAQUE_WAVES_PER_CU);
-    const size_t fixed = samples_lds_extra(c->sceneHasTransparency) + (size_t)K.tlasStackCap * 256;
+    const size_t fixed = samples_lds_extra(c->sceneHasTransparency, plan.compact) + (size_t)K.tlasStackCap * 256;
     int window = budget > fixed ? (int)((budget - fixed) / 512) : 0;
     if (const char* e = std::getenv("RZ_BLAS_STACK_WINDOW")) window = std::atoi(e);        // test aid: force a small window
     window = std::max(window, 2);
@@ -680,6 +684,15 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
         rc = ensure(c, c->dBlasOvf, (size_t)plan.grid * K.blasOvfCap * 64 * sizeof(uint2));
         if (rc != RZ_OK) return rc;
         K.blasOvf = static_cast<uint2*>(c->dBlasOvf.p);
+    }
+    K.claimScratch = nullptr;
+    if (plan.compact && K.maxBounces < 65536) {          // per resident wave: the claim's addends + the pool of parked paths (rz_scene_dev.h)
+        size_t stride = RZ_CLAIM_SCRATCH_DWORDS + RZ_CLAIM_STRIDE_PAD;
+        if (const char* e = std::getenv("RZ_CLAIM_STRIDE_PAD")) stride = RZ_CLAIM_SCRATCH_DWORDS + (size_t)std::max(0, std::atoi(e));   // tuning aid (dwords)
+        rc = ensure(c, c->dClaimScratch, (size_t)plan.grid * stride * sizeof(float));
+        if (rc != RZ_OK) return rc;
+        K.claimScratch = static_cast<float*>(c->dClaimScratch.p);
+        K.claimStride = (uint32_t)stride;
     }
     RZ_HIP(c, hipEventRecord(c->evStart[evSlot], c->stream));
     if (K.nSlots > 0) launch_render_samples(K, counted, c->sceneHasTransparency, c->stream);
@@ -841,7 +854,7 @@ void rz_destroy(rz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
-                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs, &c->dRawNodes, &c->dRawIdx, &c->dRawTris, &c->dRelayoutWs})
+                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs, &c->dRawNodes, &c->dRawIdx, &c->dRawTris, &c->dRelayoutWs, &c->dClaimScratch})
         b->release();
     if (c->wfHostCount) (void)hipHostFree(c->wfHostCount);
     if (c->tlasHostCounts) (void)hipHostFree(c->tlasHostCounts);

@@ -181,6 +181,9 @@ __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
 #ifndef RZ_GROUPS_PER_CLAIM
 #define RZ_GROUPS_PER_CLAIM 8
 #endif
+#ifndef RZ_COMPACT_DEFAULT
+#define RZ_COMPACT_DEFAULT 1     // compaction of late bounces across a claim (render_claim_compact); RZ_COMPACT=0/1 overrides at run time
+#endif
 template <bool COUNT, bool GLASS, bool OVF>
 __device__ __forceinline__ void render_samples_group(const KParams& K, const unsigned wblock, unsigned char* lds_raw) {
     const int lane = threadIdx.x & 63;
@@ -444,7 +447,197 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
 }
 
 
-template <bool COUNT, bool GLASS, bool OVF>
+
+// ---------------------------------------------------------------------------------------------------------
+// render_claim_compact: the opaque spp >= 64 persistent path with RAY COMPACTION across the pixels of a claim
+// (north_star: "wavefront ballot / prefix-sum ray compaction for divergent bounces").
+// A claim is up to RZ_CLAIM_UNITS (pixel, 64-sample batch) units.  The wave runs the units one after the other as
+// before, but a path that is about to trace its THIRD segment (bounce >= 2: 5 % of C2's paths, scattered over lanes
+// whose neighbours have died) is parked instead: its 13 dwords of state + a back reference go to a pool in the wave's
+// scratch, at slot nPool + (number of parked lanes below it) -- a ballot and a popcount of the lower lanes.  When the
+// claim's units are through, the pool is worked off 64 paths at a time: full waves instead of 8 x 44 / 8 x 21 live
+// lanes (C2), with the same trace / advance code (ONE inlined copy serves both phases).  The two addends of every
+// sample go to the wave's scratch instead of LDS (the pixel's ordered sum needs the parked samples' sky term), and
+// the ordered sums of the whole claim run at its end, one lane per (pixel, colour channel): 24 lanes at once instead
+// of 3 lanes eight times.  A path's arithmetic does not depend on where it runs: same bits.
+// Scratch is private to the resident wave and is only ever read by the wave that wrote it (L1/L2 hits); the
+// __syncthreads() of the one-wave workgroup order its stores before its loads.
+template <bool COUNT, bool OVF>
+__device__ __forceinline__ void render_claim_compact(const KParams& K, const unsigned base, const unsigned end, unsigned char* lds_raw) {
+    const int lane = threadIdx.x & 63;
+    const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + lane,
+                               OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + lane : nullptr, K.blasStackCap};
+    int* tstk = reinterpret_cast<int*>(lds_raw + (size_t)K.blasStackCap * 64 * sizeof(uint2)) + lane;
+    float* const addBase = K.claimScratch + (size_t)blockIdx.x * K.claimStride;
+    unsigned* const pool = reinterpret_cast<unsigned*>(addBase + (size_t)RZ_CLAIM_UNITS * 6 * 64);
+    constexpr int PS = RZ_CLAIM_UNITS * 64;          // pool stride (slots per field)
+    const int spp = K.spp;
+    const int nBatches = (spp + 63) / 64;
+    const int nPix = (int)(end - base);
+    const int nUnits = nPix * nBatches;               // <= RZ_CLAIM_UNITS by the launch plan
+    int nPool = 0, unit = 0, poolBase = 0, poolWrite = 0;     // wave-uniform
+    Tally c = {};
+    Path P;
+    P.mode = MODE_DONE;
+    for (unsigned guard = 0; guard < (1u << 20); ++guard) {      // (a backstop: units + pool rounds of at most maxBounces generations)
+        const bool phase2 = unit >= nUnits;
+        int backUnit = 0, backLane = lane;
+        bool poolLane = false;
+        P.mode = MODE_DONE;
+        P.addLight = mk3(0.0f, 0.0f, 0.0f);
+        P.addSky = mk3(0.0f, 0.0f, 0.0f);
+        P.usedIor = 0;
+        P.ior = 1.0f;
+        if (!phase2) {
+            const int p = unit / nBatches, b = unit - p * nBatches;
+            const int slot = (int)base + p;
+            const int localTile = slot >> 6, l = slot & 63;
+            const int tile = localTile * K.tileNRanks + K.tileRank;
+            const int tx = tile % K.tilesX, ty = tile / K.tilesX;
+            const int px = tx * RZ_TILE_W + (l & 7), py = ty * RZ_TILE_H + (l >> 3);
+            const int s = b * 64 + lane;
+            if (slot < K.nSlots && px < K.width && py < K.height && s < spp) {
+                const float fragx = (float)px + 0.5f, fragy = (float)py + 0.5f;
+                P.uv.x = fragx / (float)K.width;
+                P.uv.y = fragy / (float)K.height;
+                P.fragSum = fragx + fragy;
+                P.color = mk3(0.0f, 0.0f, 0.0f);
+                P.samp = K.sampleBase + s;
+                begin_sample<COUNT>(K, P, c);
+            }
+        } else {
+            if (poolBase >= nPool) {            // this generation is through: the paths it left behind form the next one
+                if (poolWrite == 0) break;
+                nPool = poolWrite; poolBase = 0; poolWrite = 0;
+                __syncthreads();
+            }
+            const int sl = poolBase + lane;
+            poolLane = sl < nPool;
+            if (poolLane) {
+                P.o = mk3(__uint_as_float(pool[0 * PS + sl]), __uint_as_float(pool[1 * PS + sl]), __uint_as_float(pool[2 * PS + sl]));
+                P.d = mk3(__uint_as_float(pool[3 * PS + sl]), __uint_as_float(pool[4 * PS + sl]), __uint_as_float(pool[5 * PS + sl]));
+                P.throughput = mk3(__uint_as_float(pool[6 * PS + sl]), __uint_as_float(pool[7 * PS + sl]), __uint_as_float(pool[8 * PS + sl]));
+                P.seed.x = __uint_as_float(pool[9 * PS + sl]);
+                P.seed.y = __uint_as_float(pool[10 * PS + sl]);
+                P.samp = (int)pool[11 * PS + sl];
+                const unsigned bb = pool[12 * PS + sl];
+                P.bounce = (int)(bb >> 16);
+                backUnit = (int)((bb >> 6) & 1023u);
+                backLane = (int)(bb & 63u);
+                P.color = mk3(0.0f, 0.0f, 0.0f);
+                P.mode = MODE_SEGMENT;
+            }
+        }
+        // ONE trace / advance loop serves both phases.  Phase 1: a unit's paths run until they finish or stand in front
+        // of their third segment (bounce >= 2).  Phase 2: every pooled path runs exactly one segment (there are no shadow
+        // queries after bounce 0), so the survivors can be compacted again before the next bounce.
+        const int stopBounce = phase2 ? P.bounce + 1 : 2;
+        for (;;) {
+            const bool run = P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= stopBounce);
+            if (__ballot(run) == 0ull) break;
+            if (run) {
+                HitRec h;
+                const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, tstk, c);
+                advance<COUNT, false>(K, P, found, h, c);
+            }
+        }
+        const bool parked = P.mode != MODE_DONE;
+        const unsigned long long pm = __ballot(parked);
+        if (!phase2) {
+            float* const A = addBase + (size_t)unit * 384;
+            A[lane] = P.addLight.x; A[64 + lane] = P.addLight.y; A[128 + lane] = P.addLight.z;        // FS:717
+            A[192 + lane] = P.addSky.x; A[256 + lane] = P.addSky.y; A[320 + lane] = P.addSky.z;       // FS:709 (parked: still 0)
+            backUnit = unit;
+        } else if (poolLane && !parked) {
+            float* const A = addBase + (size_t)backUnit * 384;
+            A[192 + backLane] = P.addSky.x; A[256 + backLane] = P.addSky.y; A[320 + backLane] = P.addSky.z;
+        }
+        // compaction: parked lane -> pool slot (write cursor) + (number of parked lanes below it).  In phase 2 the write
+        // cursor trails the read cursor (a round reads 64 slots and parks at most 64), so the pool is compacted in place.
+        const int wbase = phase2 ? poolWrite : nPool;
+        if (parked) {
+            const int sl = wbase + __popcll(pm & ((1ull << lane) - 1ull));
+            pool[0 * PS + sl] = __float_as_uint(P.o.x); pool[1 * PS + sl] = __float_as_uint(P.o.y); pool[2 * PS + sl] = __float_as_uint(P.o.z);
+            pool[3 * PS + sl] = __float_as_uint(P.d.x); pool[4 * PS + sl] = __float_as_uint(P.d.y); pool[5 * PS + sl] = __float_as_uint(P.d.z);
+            pool[6 * PS + sl] = __float_as_uint(P.throughput.x); pool[7 * PS + sl] = __float_as_uint(P.throughput.y);
+            pool[8 * PS + sl] = __float_as_uint(P.throughput.z);
+            pool[9 * PS + sl] = __float_as_uint(P.seed.x); pool[10 * PS + sl] = __float_as_uint(P.seed.y);
+            pool[11 * PS + sl] = (unsigned)P.samp;
+            pool[12 * PS + sl] = ((unsigned)P.bounce << 16) | ((unsigned)backUnit << 6) | (unsigned)backLane;
+        }
+        if (!phase2) {
+            nPool += __popcll(pm);
+            ++unit;
+            if (unit >= nUnits) __syncthreads();       // the pool is read next
+        } else {
+            poolWrite += __popcll(pm);
+            poolBase += 64;
+        }
+    }
+    __syncthreads();
+    // ---- the claim's ordered sums: lane 3p + ch replays pixel p's additions of channel ch in sample order
+    {
+        const int p = lane / 3, ch = lane - 3 * p;
+        bool inside = false;
+        size_t pix = 0;
+        float chan = 0.0f, alpha = 0.0f;
+        if (p < nPix) {
+            const int slot = (int)base + p;
+            const int localTile = slot >> 6, l = slot & 63;
+            const int tile = localTile * K.tileNRanks + K.tileRank;
+            const int tx = tile % K.tilesX, ty = tile / K.tilesX;
+            const int px = tx * RZ_TILE_W + (l & 7), py = ty * RZ_TILE_H + (l >> 3);
+            if (slot < K.nSlots && px < K.width && py < K.height) {
+                inside = true;
+                pix = (size_t)py * K.width + px;
+                if (K.sampleBase != 0) {
+                    const float4 a = K.accum[pix];
+                    chan = ch == 0 ? a.x : (ch == 1 ? a.y : a.z);
+                    alpha = a.w;
+                }
+            }
+        }
+        if (inside) {
+            for (int b = 0; b < nBatches; ++b) {
+                const float* Lf = addBase + (size_t)(p * nBatches + b) * 384 + 64 * ch;
+                const float* Sf = Lf + 192;
+                const int n = min(64, spp - b * 64);
+                int k = 0;
+                for (; k + 8 <= n; k += 8) {
+                    float l[8], q[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { l[u] = Lf[k + u]; q[u] = Sf[k + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { chan = chan + l[u]; chan = chan + q[u]; }   // FS:717, FS:709
+                }
+                for (; k < n; ++k) { chan = chan + Lf[k]; chan = chan + Sf[k]; }
+            }
+        }
+        const int l0 = 3 * p < 64 ? 3 * p : 0;
+        const float cx = __shfl(chan, l0), cy = __shfl(chan, (l0 + 1) & 63), cz = __shfl(chan, (l0 + 2) & 63);
+        if (inside && ch == 0) {
+            K.accum[pix] = make_float4(cx, cy, cz, alpha + (float)spp);
+            K.ior[pix] = 1.0f;
+        }
+        if (COUNT) {
+            const unsigned long long im = __ballot(inside && ch == 0);
+            if (lane == 0 && im) atomicAdd(&K.counters->pixels, (unsigned long long)__popcll(im));
+        }
+    }
+    if (COUNT) {
+        unsigned v[9] = {c.samples, c.traversals, c.tlas_nodes, c.tlas_leaf_indices, c.instances, c.blas_nodes,
+                         c.triangles, c.materials, c.light_fetches};
+        unsigned long long* g = reinterpret_cast<unsigned long long*>(K.counters);
+        for (int k = 0; k < 9; ++k) {
+            unsigned x = v[k];
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+            if (lane == 0 && x) atomicAdd(&g[k], (unsigned long long)x);
+        }
+    }
+    __syncthreads();        // the next claim overwrites the scratch
+}
+
+template <bool COUNT, bool GLASS, bool OVF, bool COMPACT>
 __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES_MIN_WAVES) void rz_render_samples(const KParams K, const unsigned nGroups, const unsigned perClaim) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if (perClaim == 0) {                        // one workgroup per pixel group (small launches, spp < 64)
@@ -457,7 +650,11 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= nGroups) break;             // every wave of the grid reaches this: the counter only grows
         const unsigned end = base + perClaim < nGroups ? base + perClaim : nGroups;
-        for (unsigned wb = base; wb < end; ++wb) render_samples_group<COUNT, GLASS, OVF>(K, wb, lds_raw);
+        if constexpr (COMPACT && !GLASS) {
+            render_claim_compact<COUNT, OVF>(K, base, end, lds_raw);
+        } else {
+            for (unsigned wb = base; wb < end; ++wb) render_samples_group<COUNT, GLASS, OVF>(K, wb, lds_raw);
+        }
     }
 }
 
@@ -515,7 +712,7 @@ void dump_wave_log(int nWaves) {
 // Persistent waves pay off when a group is one pixel's 64-sample batches and there are many groups per resident wave
 // (C2: 17.2 -> 16.8 ms, C5: 226 -> 203 ms).  With several pixels per wave (spp < 64) or a small frame the hardware
 // dispatcher is the better scheduler (C4: 14.6 ms against 15.4-19.9 ms persistent; C1: 0.04 against 0.1-0.2).
-SamplesPlan plan_render_samples(int spp, int nSlots) {
+SamplesPlan plan_render_samples(int spp, int nSlots, bool glass) {
     SamplesPlan p{};
     const int pixPerWave = spp >= 64 ? 1 : 64 / spp;
     p.groups = ((long long)nSlots + pixPerWave - 1) / pixPerWave;
@@ -527,30 +724,43 @@ SamplesPlan plan_render_samples(int spp, int nSlots) {
     }
     p.perClaim = (spp >= 64 && p.groups >= (long long)nCU * RZ_PERSIST_WAVES_PER_CU * 16) ? RZ_GROUPS_PER_CLAIM : 0;
     if (const char* e = std::getenv("RZ_GROUPS_PER_CLAIM")) p.perClaim = std::max(0, std::atoi(e));      // tuning aid
+    // ray compaction across the units of a claim (render_claim_compact): opaque scenes, persistent launches, and a claim
+    // must hold at most RZ_CLAIM_UNITS (pixel, 64-sample batch) units
+    const int nBatches = (spp + 63) / 64;
+    bool compact = RZ_COMPACT_DEFAULT != 0;
+    if (const char* e = std::getenv("RZ_COMPACT")) compact = std::atoi(e) != 0;                            // A/B aid
+    // (measured: C2, 64 spp, 14.29 -> 13.28 ms; 128 spp C5 144.2 -> 143.0; at 256 spp a claim is 2 pixels and the gain is gone)
+    p.compact = compact && !glass && p.perClaim > 0 && nBatches <= 2;
+    if (p.compact) p.perClaim = std::max(1, std::min(p.perClaim, RZ_CLAIM_UNITS / nBatches));
     const long long claims = p.perClaim ? (p.groups + p.perClaim - 1) / p.perClaim : p.groups;
     p.grid = p.perClaim ? std::min<long long>(claims, (long long)nCU * RZ_PERSIST_WAVES_PER_CU) : p.groups;
     return p;
 }
-size_t samples_lds_extra(bool glass) {      // LDS per wave besides the two stacks
+size_t samples_lds_extra(bool glass, bool compact) {      // LDS per wave besides the two stacks
+    if (compact) return 0;                                // addends live in the claim scratch
     return glass ? 4 * 64 * sizeof(float4) + 3 * 64 * sizeof(int) : 6 * 64 * sizeof(float);
 }
 
 void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream_t stream) {
-    const SamplesPlan plan = plan_render_samples(K.spp, K.nSlots);
+    const SamplesPlan plan = plan_render_samples(K.spp, K.nSlots, glass);
     const long long blocks = plan.groups, grid = plan.grid, perClaim = plan.perClaim;
     if (blocks <= 0) return;
-    const size_t lds = (size_t)K.blasStackCap * 64 * sizeof(uint2) + (size_t)K.tlasStackCap * 64 * sizeof(int) + samples_lds_extra(glass);
+    const bool compact = plan.compact && K.claimScratch != nullptr;
+    const size_t lds = (size_t)K.blasStackCap * 64 * sizeof(uint2) + (size_t)K.tlasStackCap * 64 * sizeof(int) + samples_lds_extra(glass, compact);
     const dim3 g((unsigned)grid), b(64);
     const unsigned nGroups = (unsigned)blocks;
     if (perClaim && hipMemsetAsync(K.groupCounter, 0, sizeof(unsigned), stream) != hipSuccess) return;
     const bool ovf = K.blasOvfCap > 0;           // only set for persistent launches (rz_context.hip: render_samples)
-#define RZ_LAUNCH_SAMPLES(C, G, O) hipLaunchKernelGGL((rz_render_samples<C, G, O>), g, b, lds, stream, K, nGroups, (unsigned)perClaim)
+#define RZ_LAUNCH_SAMPLES(C, G, O, M) hipLaunchKernelGGL((rz_render_samples<C, G, O, M>), g, b, lds, stream, K, nGroups, (unsigned)perClaim)
     if (glass) {
-        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, true, true); else RZ_LAUNCH_SAMPLES(true, true, false); }
-        else { if (ovf) RZ_LAUNCH_SAMPLES(false, true, true); else RZ_LAUNCH_SAMPLES(false, true, false); }
+        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, true, true, false); else RZ_LAUNCH_SAMPLES(true, true, false, false); }
+        else { if (ovf) RZ_LAUNCH_SAMPLES(false, true, true, false); else RZ_LAUNCH_SAMPLES(false, true, false, false); }
+    } else if (compact) {
+        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, false, true, true); else RZ_LAUNCH_SAMPLES(true, false, false, true); }
+        else { if (ovf) RZ_LAUNCH_SAMPLES(false, false, true, true); else RZ_LAUNCH_SAMPLES(false, false, false, true); }
     } else {
-        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, false, true); else RZ_LAUNCH_SAMPLES(true, false, false); }
-        else { if (ovf) RZ_LAUNCH_SAMPLES(false, false, true); else RZ_LAUNCH_SAMPLES(false, false, false); }
+        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, false, true, false); else RZ_LAUNCH_SAMPLES(true, false, false, false); }
+        else { if (ovf) RZ_LAUNCH_SAMPLES(false, false, true, false); else RZ_LAUNCH_SAMPLES(false, false, false, false); }
     }
 #undef RZ_LAUNCH_SAMPLES
 }

@@ -104,10 +104,21 @@ struct KParams {
     float camPos[3];
     int32_t blasOvfCap;     // entries per lane beyond the LDS window, kept in global memory (persistent launches only; else 0)
     uint2* blasOvf;         // [resident wave][blasOvfCap][64 lanes]
+    float* claimScratch;    // compacting launches (rz_kernels.hip: render_claim_compact): per resident wave, addends + survivor pool
+    uint32_t claimStride;   // dwords from one resident wave's scratch to the next (>= RZ_CLAIM_SCRATCH_DWORDS)
 };
 
 // How rz_render_samples is launched (rz_kernels.hip: plan_render_samples): groups of pixels, the grid, and the number
 // of groups a persistent wave claims per atomic (0: one workgroup per group).
-struct SamplesPlan { long long groups, grid; int perClaim; };
+struct SamplesPlan { long long groups, grid; int perClaim; bool compact; };
+
+// Per resident wave of a compacting launch: the two addends of every sample of up to RZ_CLAIM_UNITS (pixel, batch) units
+// [unit][6][64] floats, then the pool of parked paths [RZ_POOL_FIELDS][RZ_CLAIM_UNITS * 64] dwords.
+#ifndef RZ_CLAIM_UNITS_N
+#define RZ_CLAIM_UNITS_N 8
+#endif
+constexpr int RZ_CLAIM_UNITS = RZ_CLAIM_UNITS_N;
+constexpr int RZ_POOL_FIELDS = 14;
+constexpr size_t RZ_CLAIM_SCRATCH_DWORDS = (size_t)RZ_CLAIM_UNITS * 6 * 64 + (size_t)RZ_POOL_FIELDS * RZ_CLAIM_UNITS * 64;
 
 }  // namespace rz

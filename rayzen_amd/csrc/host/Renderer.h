@@ -9,6 +9,8 @@
 // Unlike the reference's per-frame path, updateDynamicBVHAndSSBOs re-uploads
 // only what changed (instances + TLAS, a few KB), not all geometry.
 #pragma once
+#include <cstring>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -52,6 +54,55 @@ public:
         up(RZ_BIND_TLAS_INDICES, buffers_.tlasTriIndices);
         up(RZ_BIND_BLAS_NODES, buffers_.allBLASNodes);
         up(RZ_BIND_BLAS_INDICES, buffers_.allBLASTriIndices);
+        up(RZ_BIND_INSTANCES, buffers_.meshInstances);
+    }
+    // initializeSSBOs with the geometry half on the GPU (rz_build_geometry): one BLAS per distinct Mesh is built on the
+    // device and stays there as bindings 7 / 8; only instances, the TLAS, materials and lights are assembled here and
+    // uploaded.  Frames are the same bits as after initializeSSBOs(scene, /*shareMeshes=*/true).
+    void initializeSSBOsOnDevice(const Scene& scene) {
+        static const Mesh kEmpty;
+        std::map<const Mesh*, size_t> index;
+        std::vector<rz_mesh_build> built;
+        SceneBuffers b;
+        std::vector<size_t> meshOf(scene.gameObjects.size());
+        for (size_t i = 0; i < scene.gameObjects.size(); ++i) {
+            const Mesh* mesh = scene.gameObjects[i].mesh ? scene.gameObjects[i].mesh.get() : &kEmpty;
+            auto it = index.find(mesh);
+            if (it == index.end()) {
+                it = index.emplace(mesh, built.size()).first;
+                rz_mesh_build m{};
+                m.first_triangle = b.allTriangles.size(); m.n_triangles = mesh->triangles.size();
+                built.push_back(m);
+                b.allTriangles.insert(b.allTriangles.end(), mesh->triangles.begin(), mesh->triangles.end());
+            }
+            meshOf[i] = it->second;
+        }
+        check(rz_build_geometry(ctx_, reinterpret_cast<const rz_triangle*>(b.allTriangles.data()), b.allTriangles.size(), built.data(),
+                                built.size()), "rz_build_geometry");
+        std::vector<BVHNode> worldRootNodes;
+        for (size_t i = 0; i < scene.gameObjects.size(); ++i) {
+            const rz_mesh_build& m = built[meshOf[i]];
+            BVHNode root;
+            std::memcpy(static_cast<void*>(&root), &m.root, sizeof root);
+            worldRootNodes.push_back(worldRootNode(root, scene.gameObjects[i].transform));      // main.cpp:974-993
+            b.blasRoots.push_back(root);
+            BVHInstance inst;
+            inst.blasNodeOffset = m.node_offset; inst.blasTriOffset = m.index_offset;
+            inst.globalTriOffset = (int)m.first_triangle; inst.meshIndex = (int)i;
+            inst.transform = scene.gameObjects[i].transform;
+            inst.inverseTransform = inverse(scene.gameObjects[i].transform);
+            b.meshInstances.push_back(inst);
+            b.maxBLASDepth = std::max(b.maxBLASDepth, (int)m.depth);
+        }
+        BVH tlas;
+        tlas.buildTLAS(b.meshInstances, worldRootNodes);
+        b.tlasNodes = tlas.nodes; b.tlasTriIndices = tlas.triIndices; b.tlasDepth = tlas.depth();
+        b.blasBuilder = buffers_.blasBuilder;
+        buffers_ = std::move(b);
+        up(RZ_BIND_MATERIALS, scene.materials);
+        up(RZ_BIND_LIGHTS, scene.lights);
+        up(RZ_BIND_TLAS_NODES, buffers_.tlasNodes);
+        up(RZ_BIND_TLAS_INDICES, buffers_.tlasTriIndices);
         up(RZ_BIND_INSTANCES, buffers_.meshInstances);
     }
     void updateDynamicBVHAndSSBOs(const Scene& scene) {

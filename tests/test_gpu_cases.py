@@ -212,6 +212,11 @@ def test_cpp_frontend_example_builds_and_renders(tmp_path):
     assert data.startswith(b"P6\n96 54\n255\n") and len(data) == len(b"P6\n96 54\n255\n") + 96 * 54 * 3
     px = np.frombuffer(data[len(b"P6\n96 54\n255\n"):], np.uint8).reshape(54, 96, 3)
     assert px[0].mean() > 60 and px.std() > 10           # sky on top, not a constant image
+    # the same frontend with the BLAS built and kept on the GPU (Renderer::initializeSSBOsOnDevice -> rz_build_geometry)
+    ppm2 = str(tmp_path / "o2.ppm")
+    out = subprocess.run([exe, ppm2, "96", "54", "2", "2", "device"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert open(ppm2, "rb").read() == data
 
 
 # ---- the one-lane-per-sample path (scenes without transparent triangles) ------------------------------------
