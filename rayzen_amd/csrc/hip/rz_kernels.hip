@@ -476,6 +476,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
     const int nPix = (int)(end - base);
     const int nUnits = nPix * nBatches;               // <= RZ_CLAIM_UNITS by the launch plan
     int nPool = 0, unit = 0, poolBase = 0, poolWrite = 0;     // wave-uniform
+    int tileCached = -1, tileX = 0, tileY = 0;                // wave-uniform: the tile of the current unit
     Tally c = {};
     Path P;
     P.mode = MODE_DONE;
@@ -489,12 +490,16 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
         P.usedIor = 0;
         P.ior = 1.0f;
         if (!phase2) {
-            const int p = unit / nBatches, b = unit - p * nBatches;
+            const int p = nBatches == 1 ? unit : unit / nBatches, b = unit - p * nBatches;
             const int slot = (int)base + p;
             const int localTile = slot >> 6, l = slot & 63;
-            const int tile = localTile * K.tileNRanks + K.tileRank;
-            const int tx = tile % K.tilesX, ty = tile / K.tilesX;
-            const int px = tx * RZ_TILE_W + (l & 7), py = ty * RZ_TILE_H + (l >> 3);
+            if (localTile != tileCached) {      // (wave-uniform; a claim lies within one tile unless its size does not divide 64)
+                tileCached = localTile;
+                const int tile = localTile * K.tileNRanks + K.tileRank;
+                tileY = tile / K.tilesX;        // the integer division costs ~40 instructions: once per claim, not per unit
+                tileX = tile - tileY * K.tilesX;
+            }
+            const int px = tileX * RZ_TILE_W + (l & 7), py = tileY * RZ_TILE_H + (l >> 3);
             const int s = b * 64 + lane;
             if (slot < K.nSlots && px < K.width && py < K.height && s < spp) {
                 const float fragx = (float)px + 0.5f, fragy = (float)py + 0.5f;
@@ -584,8 +589,12 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
         if (p < nPix) {
             const int slot = (int)base + p;
             const int localTile = slot >> 6, l = slot & 63;
-            const int tile = localTile * K.tileNRanks + K.tileRank;
-            const int tx = tile % K.tilesX, ty = tile / K.tilesX;
+            int tx = tileX, ty = tileY;         // the last unit's tile: the right one unless the claim straddles two tiles
+            if (localTile != tileCached) {
+                const int tile = localTile * K.tileNRanks + K.tileRank;
+                ty = tile / K.tilesX;
+                tx = tile - ty * K.tilesX;
+            }
             const int px = tx * RZ_TILE_W + (l & 7), py = ty * RZ_TILE_H + (l >> 3);
             if (slot < K.nSlots && px < K.width && py < K.height) {
                 inside = true;
