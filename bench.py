@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--mesh-n", type=int, default=76, help="bunny stand-in has 12*n*n triangles")
     ap.add_argument("--obj", default=None, help="render this OBJ instead of the procedural stand-in (default: assets/bunny.obj if present)")
-    ap.add_argument("--backend", choices=["auto", "pixel", "wavefront"], default="auto",
+    ap.add_argument("--backend", choices=["auto", "pixel"], default="auto",
                     help="render pipeline: auto = the library's default")
     ap.add_argument("--reduce", choices=["group", "torch", "torch-gloo"], default="group",
                     help="group = the C-ABI's rz_group (RCCL over xGMI, the product path); torch = torch.distributed.reduce on the "
@@ -105,7 +105,7 @@ def main():
     # a real bunny.obj dropped into assets/ replaces the procedural stand-in; none ships with the repo
     obj = a.obj or (os.path.join(ROOT, "assets", "bunny.obj") if os.path.exists(os.path.join(ROOT, "assets", "bunny.obj")) else None)
     sc = S.bunny_scene(n=a.mesh_n, aspect=W / H, obj_path=obj)
-    flags = {"auto": 0, "pixel": 1, "wavefront": 2}[a.backend]
+    flags = {"auto": 0, "pixel": 1}[a.backend]
     fp = frame_params(sc.camera, W, H, len(sc.lights), bounces, spp_total, 0, rank, world)
 
     group = None

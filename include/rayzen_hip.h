@@ -152,7 +152,6 @@ typedef struct rz_ctx rz_ctx;
  * failure (query rz_last_error(NULL)). */
 #define RZ_FLAG_NONE          0u  /* default: one lane per sample (rz_render_samples)                         */
 #define RZ_FLAG_MEGAKERNEL    1u  /* one lane per pixel, samples in sequence (rz_render_pixels): cross-check  */
-#define RZ_FLAG_WAVEFRONT     2u  /* queued pipeline wf_init/wf_trace/wf_shade: bit-identical, slower, opt-in */
 #define RZ_FLAG_HOST_RELAYOUT 4u  /* re-lay the scene out on the host instead of on the device (same bytes; cross-check) */
 rz_ctx*     rz_create(int device, unsigned flags);
 void        rz_destroy(rz_ctx* ctx);
@@ -275,7 +274,7 @@ int rz_last_render_ms(rz_ctx* ctx, float* ms, int* launches);
 int rz_render_history_ms(rz_ctx* ctx, float* ms, int cap);
 /* Name of the render kernel the last rz_render used (the one those event pairs bracket): the library picks
  * "rz_render_samples" (one lane per sample; "rz_render_samples<glass>" when a triangle uses a transparent material
- * and currentIor is speculated), "rz_render_pixels" (RZ_FLAG_MEGAKERNEL) or "wf_trace+wf_shade" (RZ_FLAG_WAVEFRONT). */
+ * and currentIor is speculated) or "rz_render_pixels" (RZ_FLAG_MEGAKERNEL). */
 const char* rz_last_kernel_name(const rz_ctx* ctx);
 
 /* Device pointer of the accumulation buffer currently in use. */

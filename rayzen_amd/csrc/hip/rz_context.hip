@@ -24,7 +24,6 @@
 
 #include "rayzen_hip.h"
 #include "rz_scene_dev.h"
-#include "rz_wavefront.h"
 
 namespace rz {
 struct TlasWork {       // rz_tlas_device.hip
@@ -134,18 +133,12 @@ struct rz_ctx {
     bool haveFrame = false;
     rz_frame_params frame{};
     DevBuf ownAccum, dIor;
-    // queued pipeline (rz_wavefront.hip)
-    DevBuf wfState, wfQueues, wfCounts;
     // device-side dynamic update (rz_update_transforms)
     DevBuf dXforms, dInstRef, dTlasScratch, dProjBoxes, dBuildWs;
     int* tlasHostCounts = nullptr;      // pinned: node count, index count, depth
     bool deviceOwnsTlas = false;        // instances + TLAS on the device are newer than the host copies
     int devTlasNodes = 0;
     bool sceneHasTransparency = true;   // some triangle uses a material with transparency > 0
-    int wfSlots = 0;
-    int wfTraceBlocks = 0;
-    int* wfHostCount = nullptr;     // pinned
-    long long lastRounds = 0;
     const char* lastKernel = "";
     void* extAccum = nullptr;
     size_t extAccumBytes = 0;
@@ -582,75 +575,6 @@ int finalize(rz_ctx* c) {
 #define RZ_CLAIM_STRIDE_PAD 0      // extra dwords between the scratch regions of neighbouring resident waves
 #endif
 
-constexpr int kWfMaxRounds = 16384;
-
-bool use_wavefront(const rz_ctx* c, const KParams& K) {
-    if (c->flags & RZ_FLAG_MEGAKERNEL) return false;
-    if (K.maxBounces > 4095 || K.nLights > 4095) return false;   // state packing of rz_wavefront.hip
-    return (c->flags & RZ_FLAG_WAVEFRONT) != 0;
-}
-
-// Queued pipeline: wf_init, then rounds of (wf_trace, wf_shade) until the queue is empty.  The queue length
-// lives on the device; rounds are enqueued blind in batches and the count is read back once per batch.
-int render_wavefront(rz_ctx* c, const KParams& K, bool counted) {
-    const int nSlots = K.nLocalTiles * 64;
-    if (nSlots <= 0) { c->lastLaunches = 0; return RZ_OK; }
-    int rc = ensure(c, c->wfState, (size_t)nSlots * 16 * 9);
-    if (rc != RZ_OK) return rc;
-    rc = ensure(c, c->wfQueues, (size_t)nSlots * 4 * 2);
-    if (rc != RZ_OK) return rc;
-    rc = ensure(c, c->wfCounts, (size_t)kWfMaxRounds * 4 * 2);
-    if (rc != RZ_OK) return rc;
-    if (!c->wfHostCount) RZ_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->wfHostCount), 64, hipHostMallocDefault));
-    WFParams Q{};
-    float4* st = static_cast<float4*>(c->wfState.p);
-    Q.rayO = st; Q.rayD = st + (size_t)nSlots; Q.hit = st + (size_t)nSlots * 2;
-    Q.s0 = st + (size_t)nSlots * 3; Q.s1 = st + (size_t)nSlots * 4; Q.s2 = st + (size_t)nSlots * 5;
-    Q.s3 = st + (size_t)nSlots * 6; Q.s4 = st + (size_t)nSlots * 7; Q.s5 = st + (size_t)nSlots * 8;
-    Q.queue[0] = static_cast<int*>(c->wfQueues.p);
-    Q.queue[1] = Q.queue[0] + nSlots;
-    Q.counts = static_cast<int*>(c->wfCounts.p);
-    Q.cursors = Q.counts + kWfMaxRounds;
-    Q.nSlots = nSlots;
-    Q.maxRounds = kWfMaxRounds - 1;
-    const size_t lds = wf_trace_lds_bytes(K);
-    if (wf_set_lds_limit(lds) != 0) return fail(c, RZ_ERR_HIP, "cannot reserve %zu B of LDS for the trace kernel", lds);
-    if (c->wfTraceBlocks <= 0) {
-        hipDeviceProp_t prop;
-        RZ_HIP(c, hipGetDeviceProperties(&prop, c->device));
-        const int perCU = std::max(1, std::min(8, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
-        c->wfTraceBlocks = prop.multiProcessorCount * perCU;
-    }
-    const int traceBlocks = std::max(1, std::min(c->wfTraceBlocks, (nSlots + 255) / 256));
-    const int shadeBlocks = std::max(1, std::min(2048, (nSlots + 1023) / 1024));
-    RZ_HIP(c, hipMemsetAsync(c->wfCounts.p, 0, (size_t)kWfMaxRounds * 4 * 2, c->stream));
-    launch_wf_init(K, Q, counted, c->stream);
-    int round = 0;
-    int launches = 1;
-    long long rounds = 0;
-    int batch = std::max(1, std::min(K.spp, 1024));     // every pixel needs at least spp closest-hit queries
-    for (;;) {
-        for (int k = 0; k < batch; ++k, ++round) launch_wf_round(K, Q, round, traceBlocks, shadeBlocks, counted, c->stream);
-        launches += 2 * batch;
-        rounds += batch;
-        RZ_HIP(c, hipGetLastError());
-        RZ_HIP(c, hipMemcpyAsync(c->wfHostCount, Q.counts + round, 4, hipMemcpyDeviceToHost, c->stream));
-        RZ_HIP(c, hipStreamSynchronize(c->stream));
-        const int alive = *c->wfHostCount;
-        if (alive <= 0) break;
-        batch = 16;
-        if (round + batch + 1 >= kWfMaxRounds) {         // recycle the counter arrays, keeping queue parity
-            RZ_HIP(c, hipMemsetAsync(c->wfCounts.p, 0, (size_t)kWfMaxRounds * 4 * 2, c->stream));
-            const int r0 = round & 1;
-            RZ_HIP(c, hipMemcpyAsync(Q.counts + r0, c->wfHostCount, 4, hipMemcpyHostToDevice, c->stream));
-            round = r0;
-        }
-    }
-    c->lastLaunches = launches;
-    c->lastRounds = rounds;
-    return RZ_OK;
-}
-
 // One lane per sample: independent samples when no triangle is transparent, speculated currentIor otherwise
 // (rz_kernels.hip).  The one-lane-per-pixel kernel remains as RZ_FLAG_MEGAKERNEL (the literal, sequential form).
 bool use_samples(const rz_ctx* c) { return (c->flags & RZ_FLAG_MEGAKERNEL) == 0; }
@@ -755,13 +679,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     // The event pair brackets the render kernels of this call (for the one-lane-per-sample path: the
     // rz_render_samples launches; its small ordered-sum kernel runs after the stop event when unchunked).
     const int slot = c->ringHead;
-    if (use_wavefront(c, K)) {
-        RZ_HIP(c, hipEventRecord(c->evStart[slot], c->stream));
-        rc = render_wavefront(c, K, counted);
-        if (rc != RZ_OK) return rc;
-        RZ_HIP(c, hipEventRecord(c->evStop[slot], c->stream));
-        c->lastKernel = "wf_trace+wf_shade";
-    } else if (use_samples(c)) {
+    if (use_samples(c)) {
         rc = render_samples(c, K, counted, slot);
         if (rc != RZ_OK) return rc;
         c->lastKernel = c->sceneHasTransparency ? "rz_render_samples<glass>" : "rz_render_samples";
@@ -787,15 +705,12 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
 #ifdef RZ_PROF
         unsigned long long pr[32];
         RZ_HIP(c, hipMemcpy(pr, static_cast<char*>(c->dCounters.p) + sizeof(DevCounters), sizeof pr, hipMemcpyDeviceToHost));
-        const bool wf = (c->flags & RZ_FLAG_WAVEFRONT) != 0;
-        if (!wf) dump_wave_log(K.nLocalTiles);
+        dump_wave_log(K.nLocalTiles);
         static const char* namesPx[] = {"blas loop iter", "leaf branch", "triangle test", "internal branch", "tlas pop", "instance enter", "outer iter", "uniform pair"};
-        static const char* namesWf[] = {"outer iter", "refill lane", "tlas step", "descend step", "leaf phase", "triangle test", "instance done", "-"};
-        const char** names = wf ? namesWf : namesPx;
+        const char** names = namesPx;
         for (int k = 0; k < 8; ++k)
             fprintf(stderr, "[rz_prof] %-16s wave-execs %12llu  lanes %14llu  avg active lanes %.1f\n", names[k], pr[2 * k], pr[2 * k + 1], pr[2 * k] ? (double)pr[2 * k + 1] / (double)pr[2 * k] : 0.0);
-        if (wf) fprintf(stderr, "[rz_prof] wave cycles: refill %llu  tlas %llu  descend %llu  leaf %llu  finish+store %llu\n", pr[16], pr[17], pr[18], pr[19], pr[20]);
-        else fprintf(stderr, "[rz_prof] wave cycles: begin %llu  trace %llu  advance %llu\n", pr[16], pr[17], pr[18]);
+        fprintf(stderr, "[rz_prof] wave cycles: begin %llu  trace %llu  advance %llu\n", pr[16], pr[17], pr[18]);
 #endif
     }
     return RZ_OK;
@@ -854,9 +769,8 @@ void rz_destroy(rz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
-                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->wfState, &c->wfQueues, &c->wfCounts, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs, &c->dRawNodes, &c->dRawIdx, &c->dRawTris, &c->dRelayoutWs, &c->dClaimScratch})
+                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs, &c->dRawNodes, &c->dRawIdx, &c->dRawTris, &c->dRelayoutWs, &c->dClaimScratch})
         b->release();
-    if (c->wfHostCount) (void)hipHostFree(c->wfHostCount);
     if (c->tlasHostCounts) (void)hipHostFree(c->tlasHostCounts);
     if (c->relayoutPinned) (void)hipHostFree(c->relayoutPinned);
     for (int i = 0; i < rz_ctx::kRing; ++i) {

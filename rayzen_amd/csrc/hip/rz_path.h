@@ -10,7 +10,8 @@
 // with two kinds of ray in flight: a path segment (primary / bounce) or one
 // iteration of a shadow query.  There is a single trace call site, lanes of
 // a wave can be in different phases while sharing the traversal loop, and the
-// same record can be parked in memory by a queued ("wavefront") pipeline.
+// same record can be parked in memory and picked up by another lane (the
+// compacting launch of rz_kernels.hip).
 // The arithmetic, statement by statement, is the shader's.
 #pragma once
 #include "rz_trace.h"

@@ -23,7 +23,7 @@ def oracle_render(scene, width, height, spp, bounces, crop=None, nthreads=8, wan
     return rzo.render(osc, fr, crop=crop, nthreads=nthreads, want_counters=want_counters)
 
 
-BACKENDS = {"auto": 0, "pixel": 1, "wavefront": 2}      # RZ_FLAG_MEGAKERNEL / RZ_FLAG_WAVEFRONT of include/rayzen_hip.h
+BACKENDS = {"auto": 0, "pixel": 1}      # RZ_FLAG_MEGAKERNEL of include/rayzen_hip.h
 
 
 def hip_render(scene, width, height, spp, bounces, counted=False, chunk=None, tile_rank=0, tile_nranks=1,

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4   # north_star: image L-inf error < 1e-4 on the accumulation buffer
 
 
-BACKENDS = ["auto", "pixel", "wavefront"]
+BACKENDS = ["auto", "pixel"]
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
