@@ -28,7 +28,7 @@
 namespace rz {
 struct TlasWork {       // rz_tlas_device.hip
     const float* transforms; DevInstance* instances; rz_bvh_instance* refInstances; TlasNode* nodes; int32_t* indices;
-    float* worldMin; float* worldMax; int32_t* order; int32_t* stack; int32_t* outCounts; int n;
+    float* worldMin; float* worldMax; int32_t* order; int32_t* stack; int32_t* outCounts; int32_t* scratch; int n;
 };
 void launch_tlas_refit(const TlasWork& W, hipStream_t s);
 // rz_blas_device.hip
@@ -853,7 +853,7 @@ static int update_transforms_impl(rz_ctx* c, const float* transforms, size_t n) 
     if (rc != RZ_OK) return rc;
     // scratch: worldMin, worldMax (3n floats each), order + depth (2n+8 ints... the depth stack shares order's tail), stack 3*(2n+8), counts 16
     const size_t stackInts = 3 * (2 * n + 8), orderInts = n + (2 * n + 8);
-    rc = ensure(c, c->dTlasScratch, (6 * n) * 4 + orderInts * 4 + stackInts * 4 + 64);
+    rc = ensure(c, c->dTlasScratch, (6 * n) * 4 + orderInts * 4 + stackInts * 4 + 64 + (4 * n + 8 * (n + 1)) * 4);
     if (rc != RZ_OK) return rc;
     // the reference-layout records keep their offsets: seed them from the host copy once per host-side change
     RZ_HIP(c, hipMemcpyAsync(c->dInstRef.p, c->host[RZ_BIND_INSTANCES].data(), n * sizeof(rz_bvh_instance), hipMemcpyHostToDevice, c->stream));
@@ -870,6 +870,7 @@ static int update_transforms_impl(rz_ctx* c, const float* transforms, size_t n) 
     W.order = reinterpret_cast<int32_t*>(W.worldMax + 3 * n);
     W.stack = W.order + orderInts;
     W.outCounts = W.stack + stackInts;
+    W.scratch = W.outCounts + 16;
     W.n = (int)n;
     launch_tlas_refit(W, c->stream);
     RZ_HIP(c, hipGetLastError());

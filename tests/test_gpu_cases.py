@@ -310,7 +310,7 @@ def test_device_side_tlas_rebuild_is_byte_identical_to_the_host_builder():
     r.close()
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 40])
+@pytest.mark.parametrize("n", [1, 2, 5, 40, 64, 65, 130, 700, 3000])
 def test_device_tlas_matches_host_for_random_transforms(n):
     from rayzen_amd.renderer import Renderer
     rng = np.random.default_rng(n)
@@ -322,9 +322,11 @@ def test_device_tlas_matches_host_for_random_transforms(n):
     r.upload_scene(sc)
     xf = []
     for i in range(n):
-        t = S.translate(S.identity(), rng.uniform(-20, 20, 3))
-        t = S.rotate(t, float(rng.uniform(0, 6.28)), rng.normal(size=3))
-        t = S.scale(t, rng.uniform(0.3, 3.0, 3))
+        # every third scene snaps positions to a coarse grid: equal centres, ties in the bounds, one-sided partitions
+        pos = rng.uniform(-20, 20, 3) if n % 3 else np.round(rng.uniform(-20, 20, 3) / 8.0) * 8.0
+        t = S.translate(S.identity(), pos)
+        t = S.rotate(t, float(rng.uniform(0, 6.28)) if n % 3 else 0.0, rng.normal(size=3))
+        t = S.scale(t, rng.uniform(0.3, 3.0, 3) if n % 3 else (1.0, 1.0, 1.0))
         xf.append(t)
         sc.set_transform(ids[i], t)
     sc.update_dynamic()
