@@ -710,7 +710,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
         const char** names = namesPx;
         for (int k = 0; k < 8; ++k)
             fprintf(stderr, "[rz_prof] %-16s wave-execs %12llu  lanes %14llu  avg active lanes %.1f\n", names[k], pr[2 * k], pr[2 * k + 1], pr[2 * k] ? (double)pr[2 * k + 1] / (double)pr[2 * k] : 0.0);
-        fprintf(stderr, "[rz_prof] wave cycles: begin %llu  trace %llu  advance %llu\n", pr[16], pr[17], pr[18]);
+        fprintf(stderr, "[rz_prof] wave cycles: begin %llu  trace %llu  advance %llu | inside trace: descend loops %llu  leaf phases %llu  whole BLAS walks %llu\n", pr[16], pr[17], pr[18], pr[19], pr[20], pr[21]);
 #endif
     }
     return RZ_OK;

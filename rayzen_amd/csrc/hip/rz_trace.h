@@ -43,6 +43,7 @@ struct Tally {          // per-thread counts of the REFERENCE algorithm's memory
         samples;
 #ifdef RZ_PROF          // diagnostic build only: where do the lanes of a wave spend their iterations?
     unsigned p[16];
+    unsigned long long t[4];    // wave cycles (s_memtime): [0] descend loops, [1] leaf phases, [2] whole BLAS walks
 #endif
 };
 #ifdef RZ_PROF
@@ -248,6 +249,9 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
     // have left each loop level and spent more scalar instructions on exec-mask bookkeeping (~55 per descend step) than
     // vector instructions on the two box tests (~50) -- and the kernel is bound by instruction issue, scalar
     // instructions included.
+#ifdef RZ_PROF
+    const unsigned long long tw0_ = __builtin_amdgcn_s_memtime();
+#endif
     if (!go) cur = -1;
     // (the bound is a backstop, never reached: a BLAS of n nodes is walked in fewer than 2n rounds and the host has
     //  checked that the node array is a tree -- but a wave that can spin for ever takes the whole device with it)
@@ -255,6 +259,9 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
         // "while-while": walk internal nodes; a lane that reaches a leaf parks there (its own sequence of operations is
         // unchanged) until the lanes of the wave still descending are few, then the parked lanes test their leaves
         // together.  Without this the wave ran the triangle tests for ~7 of its 64 lanes at a time.
+#ifdef RZ_PROF
+        const unsigned long long td0_ = __builtin_amdgcn_s_memtime();
+#endif
         // (the lane-count test sits at the END of the body: lanes at internal nodes always advance at least one step per
         //  round of the outer loop, or one to three stragglers with nobody at a leaf would never move again)
         for (;;) {
@@ -311,6 +318,10 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
             }
             if (__popcll(__ballot(cur >= 0)) < RZ_DESCEND_MIN_LANES) break;
         }
+#ifdef RZ_PROF
+        const unsigned long long td1_ = __builtin_amdgcn_s_memtime();
+        c.t[0] += td1_ - td0_;
+#endif
         if (__ballot((cur != -1) || (sp > 0)) == 0ull) break;
         {
             // leaves: <= 4 triangles each, contiguous in leaf order, tested in order (count 0: a culled stack entry, or a
@@ -337,8 +348,14 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
                 if (!pop_entry(bstk, sp, tLoc, cur)) cur = -1;
             }
         }
+#ifdef RZ_PROF
+        c.t[1] += __builtin_amdgcn_s_memtime() - td1_;
+#endif
         RZ_SITE(c, 0);
     }
+#ifdef RZ_PROF
+    c.t[2] += __builtin_amdgcn_s_memtime() - tw0_;
+#endif
     tLocOut = tLoc;
     return best;
 }
