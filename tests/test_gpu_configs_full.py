@@ -150,3 +150,64 @@ def test_bad_alloc_inside_the_library_becomes_a_status_code():
         got = r.read_accum()
         r.close()
         assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+# ---- the compacting launch (rz_kernels.hip: render_claim_compact): opaque scene, spp >= 64, persistent grid --------------
+
+def _band_check(sc, W, H, spp, b, got, y0=None, rows=8):
+    y0 = (H // 2) // 8 * 8 if y0 is None else y0
+    ref = _oracle_bands(sc, W, H, spp, b, (y0,), rows=rows)
+    g, o = got[y0:y0 + rows], ref[y0:y0 + rows]
+    assert (g.view(np.uint32) == o.view(np.uint32)).all(), mismatch_report(g, o)
+
+
+@pytest.mark.parametrize("W,H,spp", [(1280, 1024, 64), (1283, 1021, 100), (1280, 1024, 128)])
+def test_compacting_launch_equals_the_plain_one_and_the_oracle(W, H, spp, monkeypatch):
+    """Frame sizes that are / are not multiples of the 8x8 tile, one and two 64-sample batches per pixel (the second one
+    partly filled), 5 bounces so that paths are parked and re-parked: compaction on == compaction off == oracle band."""
+    sc = S.bunny_scene(n=16, aspect=W / H)
+    b = 5
+    on = hip_render(sc, W, H, spp, b)
+    monkeypatch.setenv("RZ_COMPACT", "0")
+    off = hip_render(sc, W, H, spp, b)
+    monkeypatch.delenv("RZ_COMPACT")
+    assert (on.view(np.uint32) == off.view(np.uint32)).all(), mismatch_report(on, off)
+    assert (on[..., 3] == spp).all()
+    _band_check(sc, W, H, spp, b, on)
+
+
+def test_compacting_launch_continued_frames_tile_ranks_and_odd_claims(monkeypatch):
+    sc = S.bunny_scene(n=16, aspect=1280 / 1024)
+    W, H, b = 1280, 1024, 4
+    whole = hip_render(sc, W, H, 128, b)
+    # 128 spp as two continued calls of 64 (sample_base = 64 reads the accumulation buffer back in the claim's sum pass)
+    two = hip_render(sc, W, H, 128, b, chunk=64)
+    assert (two.view(np.uint32) == whole.view(np.uint32)).all(), mismatch_report(two, whole)
+    # three tile ranks sum to the frame
+    total = np.zeros_like(whole)
+    for r in range(3):
+        total += hip_render(sc, W, H, 128, b, tile_rank=r, tile_nranks=3)
+    assert (total.view(np.uint32) == whole.view(np.uint32)).all()
+    # claims whose size does not divide the 64 pixels of a tile straddle two tiles (the cached tile coordinates change
+    # inside a claim)
+    monkeypatch.setenv("RZ_GROUPS_PER_CLAIM", "3")
+    odd = hip_render(sc, W, H, 128, b)
+    assert (odd.view(np.uint32) == whole.view(np.uint32)).all(), mismatch_report(odd, whole)
+    monkeypatch.setenv("RZ_GROUPS_PER_CLAIM", "7")
+    odd = hip_render(sc, W, H, 64, b)
+    monkeypatch.delenv("RZ_GROUPS_PER_CLAIM")
+    ref64 = hip_render(sc, W, H, 64, b)
+    assert (odd.view(np.uint32) == ref64.view(np.uint32)).all(), mismatch_report(odd, ref64)
+    _band_check(sc, W, H, 128, b, whole)
+
+
+def test_compacting_launch_counters_equal_the_oracle_s():
+    """The instrumented (COUNT) instantiation of the compacting kernel tallies exactly the reference algorithm's touches."""
+    sc = S.bunny_scene(n=12, aspect=1280 / 1024)
+    W, H, spp, b = 1280, 1024, 64, 4
+    img, cnt = hip_render(sc, W, H, spp, b, counted=True)
+    osc, fr = oracle_scene(sc), oracle_frame(sc, W, H, spp, b)
+    ref = np.zeros_like(img)
+    _, rc = rzo.render(osc, fr, accum=ref, nthreads=16, want_counters=True)
+    assert cnt == rc
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all()
