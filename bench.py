@@ -167,11 +167,14 @@ def main():
                     frame.copy_(host)
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        # drain this rank's own work first, so that the group's RCCL communicator and torch's (the barrier) are never
+        # in flight together; then the barrier, then the device once more (the barrier itself runs on the GPU)
         if group is not None:
             group.sync()
         torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
 
     # untimed instrumented launch: exact algorithmic unit counts of THIS rank's launch
     counters = r.render_counted()
