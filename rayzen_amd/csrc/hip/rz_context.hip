@@ -26,10 +26,7 @@
 #include "rz_scene_dev.h"
 
 namespace rz {
-struct TlasWork {       // rz_tlas_device.hip
-    const float* transforms; DevInstance* instances; rz_bvh_instance* refInstances; TlasNode* nodes; int32_t* indices;
-    float* worldMin; float* worldMax; int32_t* order; int32_t* stack; int32_t* outCounts; int32_t* scratch; int n;
-};
+// rz_tlas_device.hip
 void launch_tlas_refit(const TlasWork& W, hipStream_t s);
 // rz_blas_device.hip
 size_t blas_build_workspace_bytes(size_t n);
@@ -134,7 +131,8 @@ struct rz_ctx {
     rz_frame_params frame{};
     DevBuf ownAccum, dIor;
     // device-side dynamic update (rz_update_transforms)
-    DevBuf dXforms, dInstRef, dTlasScratch, dProjBoxes, dBuildWs;
+    DevBuf dXforms, dInstRef, dTlasScratch, dProjBoxes, dBuildWs, dTlasDfs;
+    int nTlasDfs = 0;               // pop positions of the TLAS (rz_trace.h: trace_closest)
     int* tlasHostCounts = nullptr;      // pinned: node count, index count, depth
     bool deviceOwnsTlas = false;        // instances + TLAS on the device are newer than the host copies
     int devTlasNodes = 0;
@@ -339,6 +337,40 @@ int sync_host_from_device(rz_ctx* c) {
     return RZ_OK;
 }
 
+// The TLAS as the list of its nodes in the order FS:464-501 pops them (right child first), with the position that follows
+// each subtree (TlasDfs, rz_scene_dev.h).  `below` is the number of stack entries under a node when it is popped: the
+// shader's stack[64] holds no more, and the oracle drops a push that would not fit -- such a node never expands (count 0).
+// Call after tlas_depth() has accepted the array (children in range, no more pops than nodes).
+void tlas_pop_order(const rz_bvh_node* n, size_t count, const int32_t* idx, std::vector<TlasDfs>& out) {
+    out.clear();
+    if (count == 0) return;
+    struct Item { int node, below, parentPos; };
+    std::vector<Item> st;
+    std::vector<int> parent;
+    st.push_back({0, 0, -1});
+    while (!st.empty()) {
+        const Item it = st.back();
+        st.pop_back();
+        const rz_bvh_node& N = n[it.node];
+        TlasDfs R{};
+        std::memcpy(R.bmin, N.boundsMin, 12);
+        std::memcpy(R.bmax, N.boundsMax, 12);
+        R.first = N.leftFirst;
+        R.count = N.count > 0 ? N.count : (N.count < 0 && it.below + 2 <= 64 ? -1 : 0);
+        R.inst0 = N.count > 0 ? idx[N.leftFirst] : 0;
+        const int pos = (int)out.size();
+        out.push_back(R);
+        parent.push_back(it.parentPos);
+        if (N.count < 0) {                                          // (also under a node that never expands: the list is complete, like the device builder's)
+            st.push_back({N.leftFirst, it.below, pos});             // popped after the right subtree, with the same entries below it
+            st.push_back({N.leftFirst + 1, it.below + 1, pos});     // popped next, the left child below it
+        }
+    }
+    std::vector<int> size(out.size(), 1);
+    for (size_t p = out.size(); p-- > 1;) size[parent[p]] += size[p];
+    for (size_t p = 0; p < out.size(); ++p) out[p].skip = (int)p + size[p];
+}
+
 int tlas_depth(const rz_bvh_node* n, size_t count) {
     if (count == 0) return 0;
     int best = 1;
@@ -522,6 +554,12 @@ int finalize_body(rz_ctx* c) {
         if (rc != RZ_OK) return rc;
         rc = upload_vec(c, c->dTlasIdx, ti, nTi * sizeof(int32_t));
         if (rc != RZ_OK) return rc;
+        std::vector<TlasDfs> dfs;
+        tlas_pop_order(tn, nTn, ti, dfs);
+        c->nTlasDfs = (int)dfs.size();
+        rc = upload_vec(c, c->dTlasDfs, dfs.data(), dfs.size() * sizeof(TlasDfs));
+        if (rc != RZ_OK) return rc;
+        RZ_HIP(c, hipStreamSynchronize(c->stream));     // the staging vector dies at scope exit
     }
     if (c->lightDirty) {
         int rc = upload_vec(c, c->dLight, c->host[RZ_BIND_LIGHTS].data(), c->host[RZ_BIND_LIGHTS].size());
@@ -644,13 +682,13 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     K.pairs = static_cast<const DevPair*>(c->dPairs.p);
     K.tris = static_cast<const DevTri*>(c->dTris.p);
     K.instances = static_cast<const DevInstance*>(c->dInst.p);
-    K.tlasNodes = static_cast<const TlasNode*>(c->dTlasNodes.p);
+    K.tlasDfs = static_cast<const TlasDfs*>(c->dTlasDfs.p);
     K.tlasIndices = static_cast<const int32_t*>(c->dTlasIdx.p);
     K.materials = static_cast<const DevMaterial*>(c->dMat.p);
     K.lights = static_cast<const DevLight*>(c->dLight.p);
     K.accum = accum;
     K.ior = static_cast<float*>(c->dIor.p);
-    K.nTlasNodes = c->deviceOwnsTlas ? c->devTlasNodes : (int)hostCount<rz_bvh_node>(c, RZ_BIND_TLAS_NODES);
+    K.nTlasDfs = c->nTlasDfs;
     K.nLights = std::max(0, std::min<int>(f.num_lights, (int)hostCount<rz_light>(c, RZ_BIND_LIGHTS)));
     K.nMaterials = (int)hostCount<rz_material>(c, RZ_BIND_MATERIALS);
     K.width = f.width; K.height = f.height;
@@ -663,7 +701,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     K.spp = f.spp; K.sampleBase = f.sample_base;
     K.blasStackCap = std::max(1, c->maxBlasDepth - 1);
     // a pop followed by two pushes never holds more entries than the tree has levels (FS:460: stack[64])
-    K.tlasStackCap = std::min(64, std::max(2, c->tlasDepth));
+    K.tlasStackCap = 0;         // the TLAS walk keeps no stack (rz_trace.h: trace_closest)
     std::memcpy(K.invView, f.inv_view, 64);
     std::memcpy(K.invProj, f.inv_proj, 64);
     std::memcpy(K.camPos, f.cam_pos, 12);
@@ -769,7 +807,7 @@ void rz_destroy(rz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
-                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs, &c->dRawNodes, &c->dRawIdx, &c->dRawTris, &c->dRelayoutWs, &c->dClaimScratch})
+                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs, &c->dTlasDfs, &c->dRawNodes, &c->dRawIdx, &c->dRawTris, &c->dRelayoutWs, &c->dClaimScratch})
         b->release();
     if (c->tlasHostCounts) (void)hipHostFree(c->tlasHostCounts);
     if (c->relayoutPinned) (void)hipHostFree(c->relayoutPinned);
@@ -853,7 +891,9 @@ static int update_transforms_impl(rz_ctx* c, const float* transforms, size_t n) 
     if (rc != RZ_OK) return rc;
     // scratch: worldMin, worldMax (3n floats each), order + depth (2n+8 ints... the depth stack shares order's tail), stack 3*(2n+8), counts 16
     const size_t stackInts = 3 * (2 * n + 8), orderInts = n + (2 * n + 8);
-    rc = ensure(c, c->dTlasScratch, (6 * n) * 4 + orderInts * 4 + stackInts * 4 + 64 + (4 * n + 8 * (n + 1)) * 4);
+    rc = ensure(c, c->dTlasDfs, (2 * n) * sizeof(TlasDfs));
+    if (rc != RZ_OK) return rc;
+    rc = ensure(c, c->dTlasScratch, (6 * n) * 4 + orderInts * 4 + stackInts * 4 + 64 + (4 * n + 12 * (n + 1)) * 4);
     if (rc != RZ_OK) return rc;
     // the reference-layout records keep their offsets: seed them from the host copy once per host-side change
     RZ_HIP(c, hipMemcpyAsync(c->dInstRef.p, c->host[RZ_BIND_INSTANCES].data(), n * sizeof(rz_bvh_instance), hipMemcpyHostToDevice, c->stream));
@@ -865,6 +905,7 @@ static int update_transforms_impl(rz_ctx* c, const float* transforms, size_t n) 
     W.refInstances = static_cast<rz_bvh_instance*>(c->dInstRef.p);
     W.nodes = static_cast<TlasNode*>(c->dTlasNodes.p);
     W.indices = static_cast<int32_t*>(c->dTlasIdx.p);
+    W.dfs = static_cast<TlasDfs*>(c->dTlasDfs.p);
     W.worldMin = reinterpret_cast<float*>(sc);
     W.worldMax = W.worldMin + 3 * n;
     W.order = reinterpret_cast<int32_t*>(W.worldMax + 3 * n);
@@ -878,6 +919,7 @@ static int update_transforms_impl(rz_ctx* c, const float* transforms, size_t n) 
     // the caller's transform array may die after this call returns, and the TLAS depth sizes the LDS stack
     RZ_HIP(c, hipStreamSynchronize(c->stream));
     c->devTlasNodes = c->tlasHostCounts[0];
+    c->nTlasDfs = c->tlasHostCounts[0];
     c->tlasDepth = std::max(1, c->tlasHostCounts[2]);
     c->deviceOwnsTlas = true;
     return RZ_OK;

@@ -45,7 +45,6 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
     const size_t perWave = (size_t)K.blasStackCap * 64 * sizeof(uint2) + (size_t)K.tlasStackCap * 64 * sizeof(int);
     unsigned char* base = lds_raw + perWave * wave;
     const BlasStackT<false> bstk{reinterpret_cast<uint2*>(base) + lane, nullptr, K.blasStackCap};
-    int* tstk = reinterpret_cast<int*>(base + (size_t)K.blasStackCap * 64 * sizeof(uint2)) + lane;
 
     const int localTile = blockIdx.x * WAVES_PER_BLOCK + wave;
     if (localTile >= K.nLocalTiles) return;
@@ -86,7 +85,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
         if (P.mode == MODE_DONE) { RZ_SITE(c, 7); begin_sample<COUNT>(K, P, c); }
         unsigned long long t1 = __builtin_amdgcn_s_memtime();
         HitRec h;
-        const bool found = trace_closest<COUNT, false>(K, P.o, P.d, h, bstk, tstk, c);
+        const bool found = trace_closest<COUNT, false>(K, P.o, P.d, h, bstk, c);
         unsigned long long t2 = __builtin_amdgcn_s_memtime();
         advance<COUNT>(K, P, found, h, c);
         unsigned long long t3 = __builtin_amdgcn_s_memtime();
@@ -94,7 +93,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
 #else
         if (P.mode == MODE_DONE) begin_sample<COUNT>(K, P, c);
         HitRec h;
-        const bool found = trace_closest<COUNT, false>(K, P.o, P.d, h, bstk, tstk, c);
+        const bool found = trace_closest<COUNT, false>(K, P.o, P.d, h, bstk, c);
         advance<COUNT>(K, P, found, h, c);
 #endif
     }
@@ -191,7 +190,6 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
     // (the overflow columns are indexed by the RESIDENT workgroup: blasOvfCap > 0 only in persistent launches)
     const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + lane,
                                OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + lane : nullptr, K.blasStackCap};
-    int* tstk = reinterpret_cast<int*>(lds_raw + (size_t)K.blasStackCap * 64 * sizeof(uint2)) + lane;
     float4* addL = reinterpret_cast<float4*>(lds_raw + (size_t)K.blasStackCap * 64 * sizeof(uint2) +
                                              (size_t)K.tlasStackCap * 64 * sizeof(int));
 
@@ -266,7 +264,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
                 HitRec h;
-                const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, tstk, c);
+                const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, c);
 #ifdef RZ_PROF
                 const unsigned long long t2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -350,7 +348,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
                 }
                 while (P.mode != MODE_DONE) {
                     HitRec h;
-                    const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, tstk, COUNT ? att : c);
+                    const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, COUNT ? att : c);
                     advance<COUNT, true>(K, P, found, h, COUNT ? att : c);
                 }
                 if (run) {
@@ -468,7 +466,6 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
     const int lane = threadIdx.x & 63;
     const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + lane,
                                OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + lane : nullptr, K.blasStackCap};
-    int* tstk = reinterpret_cast<int*>(lds_raw + (size_t)K.blasStackCap * 64 * sizeof(uint2)) + lane;
     float* const addBase = K.claimScratch + (size_t)blockIdx.x * K.claimStride;
     unsigned* const pool = reinterpret_cast<unsigned*>(addBase + (size_t)RZ_CLAIM_UNITS * 6 * 64);
     constexpr int PS = RZ_CLAIM_UNITS * 64;          // pool stride (slots per field)
@@ -543,7 +540,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
             if (__ballot(run) == 0ull) break;
             if (run) {
                 HitRec h;
-                const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, tstk, c);
+                const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, c);
                 advance<COUNT, false>(K, P, found, h, c);
             }
         }

@@ -66,6 +66,17 @@ struct TlasNode {       // == rz_bvh_node
     float bmax[3]; int32_t count;
 };
 
+// The TLAS in the order the shader's stack loop pops it (depth first, right child before left; rz_trace.h:
+// trace_closest), one 64-B record per pop position -- one s_load_dwordx16.
+struct alignas(64) TlasDfs {
+    float bmin[3]; int32_t first;   // leaf: first entry in the TLAS index array
+    float bmax[3]; int32_t count;   // > 0 leaf (instances), < 0 internal, 0 never expands (empty root / the shader's stack[64] would be full)
+    int32_t skip;                   // the position after this node's subtree
+    int32_t inst0;                  // leaf: the instance its first entry names
+    int32_t pad[6];
+};
+static_assert(sizeof(TlasDfs) == 64, "TlasDfs is one scalar fetch");
+
 struct DevMaterial { float albedo[3], metallic, roughness, reflectivity, transparency, ior; };
 struct DevLight { float posdir[4], color[3], power; };
 
@@ -79,7 +90,7 @@ struct KParams {
     const DevPair* pairs;
     const DevTri* tris;
     const DevInstance* instances;
-    const TlasNode* tlasNodes;
+    const TlasDfs* tlasDfs;     // the TLAS in pop order (derived; the verbatim node array stays with the context for rz_present / rz_read_binding)
     const int32_t* tlasIndices;
     const DevMaterial* materials;
     const DevLight* lights;
@@ -87,7 +98,7 @@ struct KParams {
     float* ior;             // width*height: FS:674's currentIor carried across rz_render calls
     DevCounters* counters;  // only for the counting build
     unsigned* groupCounter; // next unclaimed pixel group of this launch (persistent waves, rz_kernels.hip); zeroed per launch
-    int32_t nTlasNodes;
+    int32_t nTlasDfs;
     int32_t nLights;        // min(numLights uniform, lights.length())  (FS:574-575)
     int32_t nMaterials;
     int32_t width, height;
@@ -98,7 +109,7 @@ struct KParams {
     int32_t spp, sampleBase;
     int32_t nSlots;         // nLocalTiles * 64
     int32_t blasStackCap;   // LDS entries per lane for the BLAS stack: the whole stack (max BLAS depth - 1), or a window of it
-    int32_t tlasStackCap;
+    int32_t tlasStackCap;   // 0 since the TLAS walk needs no stack (kept: the kernel-argument layout steers register allocation)
     float invView[16];
     float invProj[16];
     float camPos[3];
@@ -106,6 +117,23 @@ struct KParams {
     uint2* blasOvf;         // [resident wave][blasOvfCap][64 lanes]
     float* claimScratch;    // compacting launches (rz_kernels.hip: render_claim_compact): per resident wave, addends + survivor pool
     uint32_t claimStride;   // dwords from one resident wave's scratch to the next (>= RZ_CLAIM_SCRATCH_DWORDS)
+};
+
+// Arguments of the device TLAS rebuild (rz_tlas_device.hip: rz_tlas_refit; filled in by rz_context.hip).
+struct TlasWork {
+    const float* transforms;        // n x 16, column-major
+    DevInstance* instances;         // in/out: fwd, inv rewritten; root box / bases kept
+    rz_bvh_instance* refInstances;  // out: transform + inverseTransform (offsets kept)
+    TlasNode* nodes;                // out: 2n-1 nodes
+    int32_t* indices;               // out: n
+    TlasDfs* dfs;                   // out: the nodes in the shader's pop order (rz_trace.h: trace_closest), 2n-1 records
+    float* worldMin;                // scratch n x 3
+    float* worldMax;                // scratch n x 3
+    int32_t* order;                 // scratch n (meshIndices)
+    int32_t* stack;                 // scratch 3 x (2n+8)
+    int32_t* outCounts;             // [0] = node count, [1] = index count, [2] = depth
+    int32_t* scratch;               // 4 x n ints (ranks|flags, two pointer buffers, the permuted order) + 2 x 6 x (n + 1) (level lists)
+    int n;
 };
 
 // How rz_render_samples is launched (rz_kernels.hip: plan_render_samples): groups of pixels, the grid, and the number

@@ -32,20 +32,6 @@
 
 namespace rz {
 
-struct TlasWork {
-    const float* transforms;        // n x 16, column-major
-    DevInstance* instances;         // in/out: fwd, inv rewritten; root box / bases kept
-    rz_bvh_instance* refInstances;  // out: transform + inverseTransform (offsets kept)
-    TlasNode* nodes;                // out: 2n-1 nodes
-    int32_t* indices;               // out: n
-    float* worldMin;                // scratch n x 3
-    float* worldMax;                // scratch n x 3
-    int32_t* order;                 // scratch n (meshIndices)
-    int32_t* stack;                 // scratch 3 x (2n+8)
-    int32_t* outCounts;             // [0] = node count, [1] = index count, [2] = depth
-    int32_t* scratch;               // 4 x n ints (ranks|flags, two pointer buffers, the permuted order) + 2 x 4 x (n + 1) (level lists)
-    int n;
-};
 
 __device__ inline float gmin(float a, float b) { return (b < a) ? b : a; }   // glm::min
 __device__ inline float gmax(float a, float b) { return (a < b) ? b : a; }   // glm::max
@@ -113,11 +99,15 @@ __global__ __launch_bounds__(1024) void rz_tlas_refit(const TlasWork W) {
     int32_t* ptrA = W.scratch + n;
     int32_t* ptrB = W.scratch + 2 * n;
     int32_t* newOrder = W.scratch + 3 * n;
-    int32_t* listA = W.scratch + 4 * n;        // level lists: (node index, internal pre-order index k, start, end)
-    int32_t* listB = listA + 4 * (n + 1);
+    // level lists: (node index, internal pre-order index k, start, end, pop position, stack entries below it when popped).
+    // The pop order (right child first) is a function of the ranges too: a subtree over c instances has 2c - 1 nodes, so
+    // the right child is popped at pos + 1, the left child after the right subtree at pos + 2 (end - mid), and what
+    // follows the node's subtree at pos + 2c - 1; the left child waits below the right one (rz_context.hip: tlas_pop_order).
+    int32_t* listA = W.scratch + 4 * n;
+    int32_t* listB = listA + 6 * (n + 1);
     __shared__ int curCount, nextCount;
     if (threadIdx.x == 0) {
-        listA[0] = 0; listA[1] = 0; listA[2] = 0; listA[3] = n;
+        listA[0] = 0; listA[1] = 0; listA[2] = 0; listA[3] = n; listA[4] = 0; listA[5] = 0;
         curCount = 1; nextCount = 0;
     }
     __threadfence_block();
@@ -129,7 +119,8 @@ __global__ __launch_bounds__(1024) void rz_tlas_refit(const TlasWork W) {
         if (cnt <= 0) break;
         depth = (int)level + 1;
         for (int item = wave; item < cnt; item += nWaves) {
-            const int nidx = cur[4 * item], k = cur[4 * item + 1], start = cur[4 * item + 2], end = cur[4 * item + 3];
+            const int nidx = cur[6 * item], k = cur[6 * item + 1], start = cur[6 * item + 2], end = cur[6 * item + 3];
+            const int dpos = cur[6 * item + 4], below = cur[6 * item + 5];
             const int count = end - start;
             // -- bounds (BVH.cpp:186-191): first-of-equals extremum per axis, 64 lanes wide
             float bmin[3], bmax[3];
@@ -151,15 +142,22 @@ __global__ __launch_bounds__(1024) void rz_tlas_refit(const TlasWork W) {
                 bmin[r] = vmin; bmax[r] = vmax;
             }
             TlasNode N;
-            for (int r = 0; r < 3; ++r) { N.bmin[r] = bmin[r]; N.bmax[r] = bmax[r]; }
+            TlasDfs R = {};
+            for (int r = 0; r < 3; ++r) { N.bmin[r] = bmin[r]; N.bmax[r] = bmax[r]; R.bmin[r] = bmin[r]; R.bmax[r] = bmax[r]; }
             if (count == 1) {
                 // every leaf holds exactly one instance, so the number of leaves the reference has written before this one
                 // is `start`
                 N.leftFirst = start; N.count = 1;
-                if (lane == 0) { W.nodes[nidx] = N; W.indices[start] = W.order[start]; }
+                R.first = start; R.count = 1; R.skip = dpos + 1; R.inst0 = W.order[start];
+                if (lane == 0) { W.nodes[nidx] = N; W.indices[start] = W.order[start]; W.dfs[dpos] = R; }
                 continue;
             }
-            if (count <= 0) { N.leftFirst = 0; N.count = 0; if (lane == 0) W.nodes[nidx] = N; continue; }
+            if (count <= 0) {
+                N.leftFirst = 0; N.count = 0;
+                R.skip = dpos + 1;
+                if (lane == 0) { W.nodes[nidx] = N; W.dfs[dpos] = R; }
+                continue;
+            }
             const float ex = bmax[0] - bmin[0], ey = bmax[1] - bmin[1], ez = bmax[2] - bmin[2];
             int axis = 0;
             if (ey > ex && ey > ez) axis = 1; else if (ez > ex) axis = 2;
@@ -232,11 +230,14 @@ __global__ __launch_bounds__(1024) void rz_tlas_refit(const TlasWork W) {
                 }
             }
             N.leftFirst = 2 * k + 1; N.count = -1;
+            R.first = 2 * k + 1; R.count = below + 2 <= 64 ? -1 : 0; R.skip = dpos + 2 * count - 1;
             if (lane == 0) {
                 W.nodes[nidx] = N;
+                W.dfs[dpos] = R;
                 const int pos = atomicAdd(&nextCount, 2);
-                nxt[4 * pos] = 2 * k + 1; nxt[4 * pos + 1] = k + 1; nxt[4 * pos + 2] = start; nxt[4 * pos + 3] = mid;
-                nxt[4 * pos + 4] = 2 * k + 2; nxt[4 * pos + 5] = k + (mid - start); nxt[4 * pos + 6] = mid; nxt[4 * pos + 7] = end;
+                int32_t* L = nxt + 6 * pos;
+                L[0] = 2 * k + 1; L[1] = k + 1; L[2] = start; L[3] = mid; L[4] = dpos + 2 * (end - mid); L[5] = below;
+                L[6] = 2 * k + 2; L[7] = k + (mid - start); L[8] = mid; L[9] = end; L[10] = dpos + 1; L[11] = below + 1;
             }
         }
         __threadfence_block();

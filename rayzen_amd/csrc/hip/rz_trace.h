@@ -70,6 +70,30 @@ __device__ __forceinline__ f32x16 sload16(const void* p) {
     asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
     return r;
 }
+// ... and the narrower forms
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x8 sload8(const void* p) {
+    f32x8 r;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ f32x4s sload4(const void* p) {
+    f32x4s r;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ int sload1(const void* p) {
+    int r;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+    return r;
+}
+template <class T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) {      // tells the compiler that p is the same in every lane
+    return reinterpret_cast<const T*>(
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)p >> 32)) << 32) |
+        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)p));
+}
+
 #ifndef RZ_SCALAR_UNIFORM
 #define RZ_SCALAR_UNIFORM 1
 #endif
@@ -368,13 +392,17 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
                                              float& tLocOut, const BlasStackT<OVF>& bstk, Tally& c) {
     const v3 inv = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
     if (COUNT) c.blas_nodes += 1;            // the shader pops the root
+    // (I is wave-uniform: the instance's root box, root reference and bases come through the scalar cache)
+    const f32x8 r0 = sload8(I->rootMin);     // rootMin[3], rootEnc, rootMax[3], pairBase
+    const f32x4s r1 = sload4(&I->triBase);   // triBase, flags
     float tminRoot;
-    bool go = slab(lo, inv, I->rootMin[0], I->rootMin[1], I->rootMin[2], I->rootMax[0], I->rootMax[1], I->rootMax[2],
-                   tminRoot);
-    go = go && !(tminRoot > 1e30f) && !(I->flags & 1);
-    const int cur = I->rootEnc;
-    const DevPair* __restrict__ pairs = K.pairs + I->pairBase;
-    const DevTri* __restrict__ tris = K.tris + I->triBase;
+    bool go = slab(lo, inv, r0[0], r0[1], r0[2], r0[4], r0[5], r0[6], tminRoot);
+    const int iflags = __float_as_int(r1[1]);
+    go = go && !(tminRoot > 1e30f) && !(iflags & 1);
+    const int cur = __float_as_int(r0[3]);
+    const int triBase = __float_as_int(r1[0]);
+    const DevPair* __restrict__ pairs = K.pairs + __float_as_int(r0[7]);
+    const DevTri* __restrict__ tris = K.tris + triBase;
     int best;
 #if RZ_OCTANT_SLAB
     if constexpr (!COUNT) {
@@ -405,69 +433,77 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
     {
         best = blas_walk<COUNT, OVF, -1>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c);
     }
-    return best < 0 ? -1 : best + I->triBase;
+    return best < 0 ? -1 : best + triBase;
 }
 
-// FS:457-503.  tstk: this lane's column of the LDS TLAS stack (node ids).
+// FS:457-503 without a stack.  The shader's loop pops nodes in an order that does not depend on the ray: depth first,
+// right child before left (it pushes leftFirst, then leftFirst + 1, and pops the top).  A ray only decides which
+// subtrees are SKIPPED -- box missed, or tmin > tHit at the moment of the pop.  So the TLAS is laid out once per
+// upload / rebuild as the list of its nodes in that order (TlasDfs, rz_scene_dev.h), each with the position that
+// follows its subtree, and a lane's whole traversal state is one integer: the position it visits next.  The WAVE walks
+// the list front to back with a scalar cursor `pos`: the record at pos is fetched once through the scalar cache, the
+// lanes standing at pos test its box against their own ray and their own tHit, and move on to pos + 1 (internal, box
+// passed) or to the record's skip position.  Every lane that is not at pos stands at or behind pos's skip position
+// (it left pos's subtree, or never entered it), so the next position anybody needs is pos + 1 if some lane descended
+// and skip[pos] otherwise: no wave-wide minimum, no LDS stack, no per-lane node fetch, no uniformity test.
+// All lanes that ever enter an instance do so in the same step, with the instance record in scalar registers.
+// Same pops in the same order per lane, same culls against the same tHit: same result, same tallies.
+// (The shader's stack[64] has no overflow guard; the oracle skips a push that would not fit.  The number of entries
+//  below a node when it is popped is a property of the tree -- one per ancestor whose right subtree holds it -- so
+//  the layout marks such nodes as never expanding: count 0.)
 template <bool COUNT, bool OVF>
-__device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitRec& h, const BlasStackT<OVF>& bstk, int* tstk,
-                                              Tally& c) {
+__device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitRec& h, const BlasStackT<OVF>& bstk, Tally& c) {
     float tHit = 1e30f;
     int bestTri = -1, bestInst = -1;
     v3 bestP = mk3(0.0f, 0.0f, 0.0f);
     if (COUNT) c.traversals += 1;
     const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    int sp = 0;
-    if (K.nTlasNodes > 0) { tstk[0] = 0; sp = 1; }
-    // The TLAS loop of FS:464-501, batched like the BLAS walk: a lane whose popped node is a leaf that passed the box
-    // test PARKS it (leafCount > 0) while the other lanes keep popping, and the parked lanes then enter their
-    // instances' BLAS together.  Entering at once -- as the shader's loop does -- ran the BLAS walks of a 16-instance
-    // scene 20 lanes wide: the lanes of a wave reach their leaves in different iterations.  Every lane still pops its
-    // own stack in its own order and updates its own tHit in the shader's order: same visits, same result.
-    // Both loops are wave-uniform (ballot conditions) with predicated bodies, see blas_walk.
-    int leafFirst = 0, leafCount = 0;
-    for (unsigned round = 0; round < (1u << 24); ++round) {
-        for (;;) {
-            const bool walk = leafCount == 0 && sp > 0;
-            if (__ballot(walk) == 0ull) break;
-            if (walk) {
-                RZ_SITE(c, 4);
-                --sp;
-                const int nidx = tstk[sp * 64];
-                const float4* __restrict__ np = reinterpret_cast<const float4*>(K.tlasNodes + nidx);
-                const float4 n0 = np[0], n1 = np[1];
-                if (COUNT) c.tlas_nodes += 1;
-                float tmin;
-                if (slab(o, inv, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, tmin) && !(tmin > tHit)) {
-                    const int lf = __float_as_int(n0.w), count = __float_as_int(n1.w);
-                    if (count > 0) { leafFirst = lf; leafCount = count; }
-                    else if (count < 0 && sp + 2 <= K.tlasStackCap) {   // count == 0: the host builder's empty root
-                        tstk[sp * 64] = lf; ++sp;
-                        tstk[sp * 64] = lf + 1; ++sp;
+    int idx = 0;                                    // the position this lane visits next
+    const int nDfs = K.nTlasDfs;
+    for (int pos = 0; pos < nDfs;) {                // wave-uniform; pos strictly grows (skip > pos by construction, checked on the host)
+        const f32x16 q = sload16(K.tlasDfs + pos);
+        const bool at = idx == pos;
+        RZ_SITE(c, 4);
+        if (COUNT && at) c.tlas_nodes += 1;
+        float tmin;
+        const bool pass = at && slab(o, inv, q[0], q[1], q[2], q[4], q[5], q[6], tmin) && !(tmin > tHit);
+        const int count = __float_as_int(q[7]), skip = __float_as_int(q[8]);
+        if (count > 0) {
+            if (__ballot(pass) != 0ull) {
+                const int first = __float_as_int(q[3]);
+                for (int i = 0; i < count; ++i) {
+                    const int instIdx = i == 0 ? __float_as_int(q[9]) : sload1(K.tlasIndices + first + i);
+                    const DevInstance* __restrict__ I = K.instances + instIdx;
+                    if (pass) {
+                        if (COUNT) { c.tlas_leaf_indices += 1; c.instances += 1; }
+                        RZ_SITE(c, 5);
+                        const f32x8 m0 = sload8(I->inv);
+                        const f32x4s m1 = sload4(I->inv + 8);
+                        const float mi[12] = {m0[0], m0[1], m0[2], m0[3], m0[4], m0[5], m0[6], m0[7], m1[0], m1[1], m1[2], m1[3]};
+                        const v3 lo = x34_point(mi, o);
+                        const v3 ld = normalize(x34_dir(mi, d));
+                        float tLoc;
+                        const int tri = traverse_blas<COUNT, OVF>(K, I, lo, ld, tLoc, bstk, c);
+                        if (__ballot(tri >= 0) != 0ull) {
+                            const f32x8 f0 = sload8(I->fwd);
+                            const f32x4s f1 = sload4(I->fwd + 8);
+                            const float mf[12] = {f0[0], f0[1], f0[2], f0[3], f0[4], f0[5], f0[6], f0[7], f1[0], f1[1], f1[2], f1[3]};
+                            if (tri >= 0) {
+                                const v3 localHit = lo + ld * tLoc;              // FS:410
+                                const v3 worldHit = x34_point(mf, localHit);     // FS:484
+                                const float tWorld = length(worldHit - o);       // FS:485
+                                if (tWorld < tHit) { tHit = tWorld; bestP = worldHit; bestTri = tri; bestInst = instIdx; }
+                            }
+                        }
                     }
                 }
             }
-            if (__popcll(__ballot(leafCount == 0 && sp > 0)) < RZ_TLAS_MIN_LANES) break;
-        }
-        if (__ballot(leafCount > 0 || sp > 0) == 0ull) break;
-        if (leafCount > 0) {
-            for (int i = 0; i < leafCount; ++i) {
-                const int instIdx = K.tlasIndices[leafFirst + i];
-                const DevInstance* __restrict__ I = K.instances + instIdx;
-                if (COUNT) { c.tlas_leaf_indices += 1; c.instances += 1; }
-                RZ_SITE(c, 5);
-                const v3 lo = x34_point(I->inv, o);
-                const v3 ld = normalize(x34_dir(I->inv, d));
-                float tLoc;
-                const int tri = traverse_blas<COUNT, OVF>(K, I, lo, ld, tLoc, bstk, c);
-                if (tri >= 0) {
-                    const v3 localHit = lo + ld * tLoc;              // FS:410
-                    const v3 worldHit = x34_point(I->fwd, localHit); // FS:484
-                    const float tWorld = length(worldHit - o);       // FS:485
-                    if (tWorld < tHit) { tHit = tWorld; bestP = worldHit; bestTri = tri; bestInst = instIdx; }
-                }
-            }
-            leafCount = 0;
+            if (at) idx = skip;
+            pos = skip;
+        } else {
+            const bool down = pass && count < 0;    // count == 0: the host builder's empty root, or a node the shader's stack could not expand
+            if (at) idx = down ? pos + 1 : skip;
+            pos = __ballot(down) != 0ull ? pos + 1 : skip;
         }
     }
     if (bestTri < 0) return false;
