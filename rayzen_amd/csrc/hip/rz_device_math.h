@@ -23,6 +23,10 @@
 
 namespace rz {
 
+// Lane mask of a predicate (HIP's __ballot takes an int: the bool -> int -> bool round trip was materialised as
+// v_cndmask + v_cmp_ne in the loops whose predicate is an AND of lane masks).
+__device__ __forceinline__ unsigned long long rz_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 struct v3 { float x, y, z; };
 struct v2 { float x, y; };
 

@@ -362,7 +362,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
                     if (COUNT) tv[slot] = att;
                 }
                 __syncthreads();
-                if (firstPass && spp >= 64 && __ballot(mine && (infov[0] & 2)) == 0ull) {
+                if (firstPass && spp >= 64 && rz_ballot(mine && (infov[0] & 2)) == 0ull) {
                     // Nobody in this batch read currentIor (the usual case: most pixels never meet glass): every
                     // sample's only version is final, so add them as the opaque kernel does -- one colour channel per
                     // lane, unrolled -- instead of one lane walking 64 keyed entries (that walk alone was a third of
@@ -406,7 +406,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
                     }
                 }
                 __syncthreads();
-                if (__ballot(sumInside && consumed < nMine) == 0ull) break;
+                if (rz_ballot(sumInside && consumed < nMine) == 0ull) break;
             }
             if (COUNT && mine) tally_add(c, tv[chosen[lane]]);
             __syncthreads();
@@ -440,7 +440,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
             for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
             if (lane == 0 && x) atomicAdd(&g[k], (unsigned long long)x);
         }
-        const unsigned long long pm = __ballot(sumInside);   // lanes 0..pixPerWave-1 (lane 0 alone when spp >= 64)
+        const unsigned long long pm = rz_ballot(sumInside);   // lanes 0..pixPerWave-1 (lane 0 alone when spp >= 64)
         if (lane == 0 && pm) atomicAdd(&K.counters->pixels, (unsigned long long)__popcll(pm));
     }
 }
@@ -537,7 +537,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
         const int stopBounce = phase2 ? P.bounce + 1 : 2;
         for (;;) {
             const bool run = P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= stopBounce);
-            if (__ballot(run) == 0ull) break;
+            if (rz_ballot(run) == 0ull) break;
             if (run) {
                 HitRec h;
                 const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, c);
@@ -545,7 +545,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
             }
         }
         const bool parked = P.mode != MODE_DONE;
-        const unsigned long long pm = __ballot(parked);
+        const unsigned long long pm = rz_ballot(parked);
         if (!phase2) {
             float* const A = addBase + (size_t)unit * 384;
             A[lane] = P.addLight.x; A[64 + lane] = P.addLight.y; A[128 + lane] = P.addLight.z;        // FS:717
@@ -627,7 +627,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
             K.ior[pix] = 1.0f;
         }
         if (COUNT) {
-            const unsigned long long im = __ballot(inside && ch == 0);
+            const unsigned long long im = rz_ballot(inside && ch == 0);
             if (lane == 0 && im) atomicAdd(&K.counters->pixels, (unsigned long long)__popcll(im));
         }
     }

@@ -48,7 +48,7 @@ struct Tally {          // per-thread counts of the REFERENCE algorithm's memory
 };
 #ifdef RZ_PROF
 // slot 2k counts wave-level executions of a site (added by the first active lane), slot 2k+1 the active lanes
-#define RZ_SITE(c, k) do { (c).p[2 * (k) + 1] += 1u; if (__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) (c).p[2 * (k)] += 1u; } while (0)
+#define RZ_SITE(c, k) do { (c).p[2 * (k) + 1] += 1u; if (__lane_id() == (unsigned)(__ffsll((long long)rz_ballot(1)) - 1)) (c).p[2 * (k)] += 1u; } while (0)
 #else
 #define RZ_SITE(c, k) do { } while (0)
 #endif
@@ -105,6 +105,15 @@ struct HitRec {
     int mat;
     int inst;
 };
+
+// Number of lanes for which p holds, compared on the scalar unit (written with __popcll the compiler widened the count
+// to 64 bits and compared it with a VECTOR instruction, v_cmp_gt_u64 on an SGPR pair, plus two mask operations).
+__device__ __forceinline__ int wave_count(bool p) {
+    int n;
+    const unsigned long long m = rz_ballot(p);
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
+    return n;
+}
 
 // FS:380-388.  Returns the hit flag; tmin as the shader computes it.
 __device__ __forceinline__ bool slab(v3 o, v3 inv, float bx0, float by0, float bz0, float bx1, float by1, float bz1,
@@ -190,7 +199,7 @@ __device__ __forceinline__ bool moller_trumbore(v3 o, v3 d, v3 v0, v3 e1, v3 e2,
     // the same triangle with near-identical rays, so they tend to fail together -- and then the second cross product,
     // two dot products and the remaining comparisons (about 30 of the test's 75 instructions) are skipped.  A lane's
     // own result is unchanged: values computed past a failed test were never used.
-    if (__ballot(ok1) == 0ull) return false;
+    if (rz_ballot(ok1) == 0ull) return false;
 #endif
     v3 q = cross(s, e1);
     float v = f * dot(d, q);
@@ -279,7 +288,11 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
     if (!go) cur = -1;
     // (the bound is a backstop, never reached: a BLAS of n nodes is walked in fewer than 2n rounds and the host has
     //  checked that the node array is a tree -- but a wave that can spin for ever takes the whole device with it)
-    for (unsigned round = 0; round < (1u << 24); ++round) {
+    // (every loop here has ONE exit, at its end: with a second `break` hipcc turned the wave-uniform exit conditions into
+    //  lane masks and tested those -- four to six scalar instructions per trip instead of a compare and a branch)
+    unsigned round = 0;
+    bool alive;
+    do {
         // "while-while": walk internal nodes; a lane that reaches a leaf parks there (its own sequence of operations is
         // unchanged) until the lanes of the wave still descending are few, then the parked lanes test their leaves
         // together.  Without this the wave ran the triangle tests for ~7 of its 64 lanes at a time.
@@ -288,9 +301,9 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
 #endif
         // (the lane-count test sits at the END of the body: lanes at internal nodes always advance at least one step per
         //  round of the outer loop, or one to three stragglers with nobody at a leaf would never move again)
-        for (;;) {
+        bool more = rz_ballot(cur >= 0) != 0ull;
+        while (more) {
             const bool act = cur >= 0;
-            if (__ballot(act) == 0ull) break;
             if (act) {
                 RZ_SITE(c, 3);
                 const DevPair* pp = pairs + cur;
@@ -299,13 +312,11 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
                 bool hl, hr;
                 int lenc, renc;
 #if RZ_SCALAR_UNIFORM
-                const DevPair* upp = reinterpret_cast<const DevPair*>(
-                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)pp >> 32)) << 32) |
-                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)pp));
-                // (the builtin returns a signed int: without the (unsigned) a low half with bit 31 set sign-extended over
-                //  the high half, the comparison below then failed for every lane and the scalar path was never taken --
-                //  half of all buffer placements ran 5.7 % slower, found from a 2x TCP access count in the slow runs)
-                if (__ballot(pp != upp) == 0ull) {       // every active lane wants the same pair: one scalar fetch,
+                // (`pairs` is wave-uniform -- it comes from the instance record, a scalar fetch -- so comparing the 32-bit
+                //  node numbers does what comparing the 64-bit addresses did, and the address is computed on the scalar unit)
+                const int ucur = __builtin_amdgcn_readfirstlane(cur);
+                if (rz_ballot(cur != ucur) == 0ull) {     // every active lane wants the same pair: one scalar fetch,
+                    const DevPair* upp = pairs + ucur;
                     RZ_SITE(c, 7);                        // box values consumed straight from SGPRs
                     const f32x16 q = sload16(upp);
                     const f32x2 lx = {q[0], q[1]}, ly = {q[2], q[3]}, lz = {q[4], q[5]};
@@ -340,14 +351,14 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
                 }
                 cur = next;
             }
-            if (__popcll(__ballot(cur >= 0)) < RZ_DESCEND_MIN_LANES) break;
+            more = wave_count(cur >= 0) >= RZ_DESCEND_MIN_LANES;
         }
 #ifdef RZ_PROF
         const unsigned long long td1_ = __builtin_amdgcn_s_memtime();
         c.t[0] += td1_ - td0_;
 #endif
-        if (__ballot((cur != -1) || (sp > 0)) == 0ull) break;
-        {
+        alive = rz_ballot((cur != -1) || (sp > 0)) != 0ull;
+        if (alive) {
             // leaves: <= 4 triangles each, contiguous in leaf order, tested in order (count 0: a culled stack entry, or a
             // finished lane); a wave-uniform loop over the triangle slot, lanes with fewer triangles sit out
             const bool leaf = cur < 0;
@@ -355,10 +366,10 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
             const int first = v >> 4, count = leaf ? (v & 15) : 0;
             if (COUNT) c.triangles += (unsigned)count;
             if (leaf) RZ_SITE(c, 1);
-            for (int i = 0;; ++i) {
-                const bool test = i < count;
-                if (__ballot(test) == 0ull) break;
-                if (test) {
+            int i = 0;
+            bool any = rz_ballot(0 < count) != 0ull;
+            while (any) {
+                if (i < count) {
                     RZ_SITE(c, 2);
                     const float4* __restrict__ tp = reinterpret_cast<const float4*>(tris + first + i);
                     float4 a = tp[0], b = tp[1], cc = tp[2];
@@ -367,6 +378,8 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
                     const bool hit = moller_trumbore(lo, ld, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, cc.x), t);
                     if (hit && t < tLoc) { tLoc = t; best = first + i; }
                 }
+                ++i;
+                any = rz_ballot(i < count) != 0ull;
             }
             if (leaf) {
                 if (!pop_entry(bstk, sp, tLoc, cur)) cur = -1;
@@ -376,7 +389,7 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
         c.t[1] += __builtin_amdgcn_s_memtime() - td1_;
 #endif
         RZ_SITE(c, 0);
-    }
+    } while (alive && ++round < (1u << 24));
 #ifdef RZ_PROF
     c.t[2] += __builtin_amdgcn_s_memtime() - tw0_;
 #endif
@@ -411,11 +424,11 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
         const bool fin = (__builtin_fabsf(inv.x) < big) && (__builtin_fabsf(inv.y) < big) && (__builtin_fabsf(inv.z) < big) &&
                          inv.x != 0.0f && inv.y != 0.0f && inv.z != 0.0f;
         const int oct = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
-        const unsigned long long walkers = __ballot(go);
+        const unsigned long long walkers = rz_ballot(go);
         int uoct = -1;
         if (walkers != 0ull) {
             const int first = __builtin_amdgcn_readlane(oct, (int)__builtin_ctzll(walkers));
-            if (__ballot(go && (!fin || oct != first)) == 0ull) uoct = first;
+            if (rz_ballot(go && (!fin || oct != first)) == 0ull) uoct = first;
         }
         switch (uoct) {
             case 0: best = blas_walk<COUNT, OVF, 0>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
@@ -469,7 +482,7 @@ __device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitR
         const bool pass = at && slab(o, inv, q[0], q[1], q[2], q[4], q[5], q[6], tmin) && !(tmin > tHit);
         const int count = __float_as_int(q[7]), skip = __float_as_int(q[8]);
         if (count > 0) {
-            if (__ballot(pass) != 0ull) {
+            if (rz_ballot(pass) != 0ull) {
                 const int first = __float_as_int(q[3]);
                 for (int i = 0; i < count; ++i) {
                     const int instIdx = i == 0 ? __float_as_int(q[9]) : sload1(K.tlasIndices + first + i);
@@ -484,7 +497,7 @@ __device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitR
                         const v3 ld = normalize(x34_dir(mi, d));
                         float tLoc;
                         const int tri = traverse_blas<COUNT, OVF>(K, I, lo, ld, tLoc, bstk, c);
-                        if (__ballot(tri >= 0) != 0ull) {
+                        if (rz_ballot(tri >= 0) != 0ull) {
                             const f32x8 f0 = sload8(I->fwd);
                             const f32x4s f1 = sload4(I->fwd + 8);
                             const float mf[12] = {f0[0], f0[1], f0[2], f0[3], f0[4], f0[5], f0[6], f0[7], f1[0], f1[1], f1[2], f1[3]};
@@ -503,7 +516,7 @@ __device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitR
         } else {
             const bool down = pass && count < 0;    // count == 0: the host builder's empty root, or a node the shader's stack could not expand
             if (at) idx = down ? pos + 1 : skip;
-            pos = __ballot(down) != 0ull ? pos + 1 : skip;
+            pos = rz_ballot(down) != 0ull ? pos + 1 : skip;
         }
     }
     if (bestTri < 0) return false;
