@@ -258,20 +258,26 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
                 P.samp = K.sampleBase + s;
                 begin_sample<COUNT>(K, P, c);
             }
-            while (P.mode != MODE_DONE) {
+            // (a wave-uniform loop with a predicated body and one exit, not a per-lane `while`: see blas_walk)
+            bool anyRun = rz_ballot(P.mode != MODE_DONE) != 0ull;
+            while (anyRun) {
 #ifdef RZ_PROF
-                RZ_SITE(c, 6);
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                unsigned long long t2 = t1;
 #endif
-                HitRec h;
-                const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, c);
+                if (P.mode != MODE_DONE) {
+                    RZ_SITE(c, 6);
+                    HitRec h;
+                    const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, c);
 #ifdef RZ_PROF
-                const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+                    t2 = __builtin_amdgcn_s_memtime();
 #endif
-                advance<COUNT, false>(K, P, found, h, c);
+                    advance<COUNT, false>(K, P, found, h, c);
+                }
 #ifdef RZ_PROF
                 tTrace += t2 - t1; tAdv += __builtin_amdgcn_s_memtime() - t2;
 #endif
+                anyRun = rz_ballot(P.mode != MODE_DONE) != 0ull;
             }
             // park the addends (zeros for idle lanes: adding +0 is exact), then replay the adds in sample order
             // (channel-major [3][64] + [3][64] floats: 1.5 KB, and the channel lanes below read consecutive words)
@@ -346,6 +352,8 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
                     P.samp = K.sampleBase + s;
                     begin_sample<COUNT>(K, P, COUNT ? att : c);
                 }
+                // (a per-lane loop here: as a wave-uniform loop with a predicated body, which pays in the opaque variant, this
+                //  one lost 3 % -- 26.1 -> 27.0 ms on the glass + mirror scene)
                 while (P.mode != MODE_DONE) {
                     HitRec h;
                     const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, COUNT ? att : c);
@@ -478,7 +486,9 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
     Tally c = {};
     Path P;
     P.mode = MODE_DONE;
-    for (unsigned guard = 0; guard < (1u << 20); ++guard) {      // (a backstop: units + pool rounds of at most maxBounces generations)
+    unsigned guard = 0;
+    bool cont;
+    do {                                                        // (one exit, at the end: see blas_walk; the bound is a backstop: units + pool rounds of at most maxBounces generations)
         const bool phase2 = unit >= nUnits;
         int backUnit = 0, backLane = lane;
         bool poolLane = false;
@@ -509,11 +519,6 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
                 begin_sample<COUNT>(K, P, c);
             }
         } else {
-            if (poolBase >= nPool) {            // this generation is through: the paths it left behind form the next one
-                if (poolWrite == 0) break;
-                nPool = poolWrite; poolBase = 0; poolWrite = 0;
-                __syncthreads();
-            }
             const int sl = poolBase + lane;
             poolLane = sl < nPool;
             if (poolLane) {
@@ -535,14 +540,17 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
         // of their third segment (bounce >= 2).  Phase 2: every pooled path runs exactly one segment (there are no shadow
         // queries after bounce 0), so the survivors can be compacted again before the next bounce.
         const int stopBounce = phase2 ? P.bounce + 1 : 2;
-        for (;;) {
-            const bool run = P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= stopBounce);
-            if (rz_ballot(run) == 0ull) break;
+        // (one exit, at the end of the body: see blas_walk)
+        bool run = P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= stopBounce);
+        bool anyRun = rz_ballot(run) != 0ull;
+        while (anyRun) {
             if (run) {
                 HitRec h;
                 const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, c);
                 advance<COUNT, false>(K, P, found, h, c);
             }
+            run = P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= stopBounce);
+            anyRun = rz_ballot(run) != 0ull;
         }
         const bool parked = P.mode != MODE_DONE;
         const unsigned long long pm = rz_ballot(parked);
@@ -576,7 +584,16 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
             poolWrite += __popcll(pm);
             poolBase += 64;
         }
-    }
+        cont = true;
+        if (unit >= nUnits && poolBase >= nPool) {      // this generation is through: the paths it left behind form the next one
+            if (poolWrite == 0) {
+                cont = false;
+            } else {
+                nPool = poolWrite; poolBase = 0; poolWrite = 0;
+                __syncthreads();
+            }
+        }
+    } while (cont && ++guard < (1u << 20));
     __syncthreads();
     // ---- the claim's ordered sums: lane 3p + ch replays pixel p's additions of channel ch in sample order
     {
