@@ -464,6 +464,10 @@ int finalize_body(rz_ctx* c) {
         if (rc != RZ_OK) return rc;
     }
     if (c->geomDirty) {
+        // the traversal addresses a BLAS's pairs with a 32-bit byte offset (rz_trace.h: sload16_off): < 2^26 pairs per BLAS
+        const size_t nodesNow = c->geomOnDevice ? c->devNodes : hostCount<rz_bvh_node>(c, RZ_BIND_BLAS_NODES);
+        if (nodesNow >= ((size_t)1 << 27))
+            return fail(c, RZ_ERR_BAD_SCENE, "BLAS node array holds %zu nodes; the limit is %zu", nodesNow, ((size_t)1 << 27) - 1);
         c->views.clear(); c->hPairs.clear(); c->hTris.clear(); c->instDirty = true;
         c->devPairsUsed = c->devTrisUsed = 0; c->devTransparent = 0;
         c->layoutOnDevice = !host_relayout_forced(c);

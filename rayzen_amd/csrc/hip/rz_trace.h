@@ -70,6 +70,12 @@ __device__ __forceinline__ f32x16 sload16(const void* p) {
     asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
     return r;
 }
+// ... with the byte offset in a scalar register (unsigned, < 4 GiB): one s_lshl instead of a 64-bit shift and add
+__device__ __forceinline__ f32x16 sload16_off(const void* base, unsigned byteOffset) {
+    f32x16 r;
+    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(base), "s"(byteOffset) : "memory");
+    return r;
+}
 // ... and the narrower forms
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x8 sload8(const void* p) {
@@ -308,22 +314,35 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
                 RZ_SITE(c, 3);
                 const DevPair* pp = pairs + cur;
                 if (COUNT) c.blas_nodes += 2;        // the shader pushes, and later pops, both children
-                float tl, tr;
-                bool hl, hr;
-                int lenc, renc;
+                // The shader pushes left, then right, and pops right at once (FS:449-450, 428-430).
+                //  * right hit and not culled: continue into it; a hit left child waits on the stack with its entry distance;
+                //  * else the next pop IS the left child just pushed: enter it directly (same cull against the same tLoc)
+                //    -- no LDS round trip;
+                //  * neither box hit: pop an older entry.
+                // (a lambda run at the end of EITHER fetch path, not code after their join: joined, the two hit flags
+                //  were lane masks merged by six scalar instructions per step)
+                auto step = [&](bool hl, float tl, bool hr, float tr, int lenc, int renc) {
+                    const bool takeR = hr && !(tr > tLoc);
+                    if (hl && takeR) push_entry(bstk, sp, make_uint2((unsigned)lenc, __float_as_uint(tl)));
+                    int next = takeR ? renc : ((tl > tLoc) ? -1 : lenc);
+                    if (!hl && !takeR) {
+                        if (!pop_entry(bstk, sp, tLoc, next)) next = -1;
+                    }
+                    cur = next;
+                };
 #if RZ_SCALAR_UNIFORM
                 // (`pairs` is wave-uniform -- it comes from the instance record, a scalar fetch -- so comparing the 32-bit
                 //  node numbers does what comparing the 64-bit addresses did, and the address is computed on the scalar unit)
                 const int ucur = __builtin_amdgcn_readfirstlane(cur);
                 if (rz_ballot(cur != ucur) == 0ull) {     // every active lane wants the same pair: one scalar fetch,
-                    const DevPair* upp = pairs + ucur;
                     RZ_SITE(c, 7);                        // box values consumed straight from SGPRs
-                    const f32x16 q = sload16(upp);
+                    const f32x16 q = sload16_off(pairs, (unsigned)ucur << 6);     // (a BLAS's pairs span < 4 GiB: rz_context.hip, finalize)
                     const f32x2 lx = {q[0], q[1]}, ly = {q[2], q[3]}, lz = {q[4], q[5]};
                     const f32x2 rx = {q[6], q[7]}, ry = {q[8], q[9]}, rz = {q[10], q[11]};
+                    float tl, tr;
+                    bool hl, hr;
                     RZ_SLAB_PAIR(OCT, RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
-                    lenc = __float_as_int(q[12]);
-                    renc = __float_as_int(q[13]);
+                    step(hl, tl, hr, tr, __float_as_int(q[12]), __float_as_int(q[13]));
                 } else
 #endif
                 {
@@ -334,22 +353,11 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
 #endif
                     const f32x2 lx = {p0.x, p0.y}, ly = {p0.z, p0.w}, lz = {p1.x, p1.y};
                     const f32x2 rx = {p1.z, p1.w}, ry = {p2.x, p2.y}, rz = {p2.z, p2.w};
+                    float tl, tr;
+                    bool hl, hr;
                     RZ_SLAB_PAIR(OCT, RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
-                    lenc = __float_as_int(p3.x);
-                    renc = __float_as_int(p3.y);
+                    step(hl, tl, hr, tr, __float_as_int(p3.x), __float_as_int(p3.y));
                 }
-                // The shader pushes left, then right, and pops right at once (FS:449-450, 428-430).
-                //  * right hit and not culled: continue into it; a hit left child waits on the stack with its entry distance;
-                //  * else the next pop IS the left child just pushed: enter it directly (same cull against the same tLoc)
-                //    -- no LDS round trip;
-                //  * neither box hit: pop an older entry.
-                const bool takeR = hr && !(tr > tLoc);
-                if (hl && takeR) push_entry(bstk, sp, make_uint2((unsigned)lenc, __float_as_uint(tl)));
-                int next = takeR ? renc : ((tl > tLoc) ? -1 : lenc);
-                if (!hl && !takeR) {
-                    if (!pop_entry(bstk, sp, tLoc, next)) next = -1;
-                }
-                cur = next;
             }
             more = wave_count(cur >= 0) >= RZ_DESCEND_MIN_LANES;
         }
