@@ -539,7 +539,10 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
         // ONE trace / advance loop serves both phases.  Phase 1: a unit's paths run until they finish or stand in front
         // of their third segment (bounce >= 2).  Phase 2: every pooled path runs exactly one segment (there are no shadow
         // queries after bounce 0), so the survivors can be compacted again before the next bounce.
-        const int stopBounce = phase2 ? P.bounce + 1 : 2;
+#ifndef RZ_PARK_BOUNCE
+#define RZ_PARK_BOUNCE 2
+#endif
+        const int stopBounce = phase2 ? P.bounce + 1 : RZ_PARK_BOUNCE;
         // (one exit, at the end of the body: see blas_walk)
         bool run = P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= stopBounce);
         bool anyRun = rz_ballot(run) != 0ull;
@@ -754,7 +757,7 @@ SamplesPlan plan_render_samples(int spp, int nSlots, bool glass) {
     bool compact = RZ_COMPACT_DEFAULT != 0;
     if (const char* e = std::getenv("RZ_COMPACT")) compact = std::atoi(e) != 0;                            // A/B aid
     // (measured: C2, 64 spp, 14.29 -> 13.28 ms; 128 spp C5 144.2 -> 143.0; at 256 spp a claim is 2 pixels and the gain is gone)
-    p.compact = compact && !glass && p.perClaim > 0 && nBatches <= 2;
+    p.compact = compact && !glass && p.perClaim > 0 && nBatches <= 2 && spp >= 64;      // (a unit is ONE pixel's batch of 64 samples)
     if (p.compact) p.perClaim = std::max(1, std::min(p.perClaim, RZ_CLAIM_UNITS / nBatches));
     const long long claims = p.perClaim ? (p.groups + p.perClaim - 1) / p.perClaim : p.groups;
     p.grid = p.perClaim ? std::min<long long>(claims, (long long)nCU * RZ_PERSIST_WAVES_PER_CU) : p.groups;
