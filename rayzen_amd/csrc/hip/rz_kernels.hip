@@ -158,6 +158,13 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
 #ifndef RZ_SAMPLES_MIN_WAVES_GLASS
 #define RZ_SAMPLES_MIN_WAVES_GLASS 4
 #endif
+// Slot l of a tile -> pixel (x, y) in the tile.  One pixel per wave (spp >= 64): row-major, a claim of 8 slots is one
+// row of the tile.  Several pixels per wave (spp < 64): Morton order (x takes the even bits of l, y the odd ones), so the
+// pixels that share a wave form a compact block -- 2x2 at 16 spp, not a 4x1 strip -- and their rays start closer to each
+// other: C4 9.30 -> 9.19 ms.  (Morton order for everything moved C2 / C5 / C3 by +0.2 ... +0.5 %: the row-shaped claim
+// is at least as good for the compacting launch.)
+__device__ __forceinline__ int slot_x(int l, bool morton) { return morton ? ((l & 1) | ((l >> 1) & 2) | ((l >> 2) & 4)) : (l & 7); }
+__device__ __forceinline__ int slot_y(int l, bool morton) { return morton ? (((l >> 1) & 1) | ((l >> 2) & 2) | ((l >> 3) & 4)) : (l >> 3); }
 __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
     a.traversals += b.traversals; a.tlas_nodes += b.tlas_nodes; a.tlas_leaf_indices += b.tlas_leaf_indices;
     a.instances += b.instances; a.blas_nodes += b.blas_nodes; a.triangles += b.triangles; a.materials += b.materials;
@@ -207,7 +214,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
         const int localTile = slot >> 6, l = slot & 63;
         const int tile = localTile * K.tileNRanks + K.tileRank;
         const int tx = tile % K.tilesX, ty = tile / K.tilesX;
-        const int px = tx * RZ_TILE_W + (l & 7), py = ty * RZ_TILE_H + (l >> 3);
+        const int px = tx * RZ_TILE_W + slot_x(l, spp < 64), py = ty * RZ_TILE_H + slot_y(l, spp < 64);
         if (px < K.width && py < K.height) {
             inside = true;
             const float fragx = (float)px + 0.5f, fragy = (float)py + 0.5f;
@@ -221,7 +228,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
         const int localTile = sumSlot >> 6, l = sumSlot & 63;
         const int tile = localTile * K.tileNRanks + K.tileRank;
         const int tx = tile % K.tilesX, ty = tile / K.tilesX;
-        const int px = tx * RZ_TILE_W + (l & 7), py = ty * RZ_TILE_H + (l >> 3);
+        const int px = tx * RZ_TILE_W + slot_x(l, spp < 64), py = ty * RZ_TILE_H + slot_y(l, spp < 64);
         if (px < K.width && py < K.height) {
             sumInside = true;
             sumPix = (size_t)py * K.width + px;
@@ -507,7 +514,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
                 tileY = tile / K.tilesX;        // the integer division costs ~40 instructions: once per claim, not per unit
                 tileX = tile - tileY * K.tilesX;
             }
-            const int px = tileX * RZ_TILE_W + (l & 7), py = tileY * RZ_TILE_H + (l >> 3);
+            const int px = tileX * RZ_TILE_W + slot_x(l, false), py = tileY * RZ_TILE_H + slot_y(l, false);
             const int s = b * 64 + lane;
             if (slot < K.nSlots && px < K.width && py < K.height && s < spp) {
                 const float fragx = (float)px + 0.5f, fragy = (float)py + 0.5f;
@@ -613,7 +620,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
                 ty = tile / K.tilesX;
                 tx = tile - ty * K.tilesX;
             }
-            const int px = tx * RZ_TILE_W + (l & 7), py = ty * RZ_TILE_H + (l >> 3);
+            const int px = tx * RZ_TILE_W + slot_x(l, spp < 64), py = ty * RZ_TILE_H + slot_y(l, spp < 64);
             if (slot < K.nSlots && px < K.width && py < K.height) {
                 inside = true;
                 pix = (size_t)py * K.width + px;

@@ -486,8 +486,11 @@ __device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitR
         const bool at = idx == pos;
         RZ_SITE(c, 4);
         if (COUNT && at) c.tlas_nodes += 1;
+        // (evaluated by every lane and combined without short-circuits: the test is straight-line code either way, and a
+        //  flag defined under `at && ...` came back from its branch as a lane mask that the ballots below had to rebuild)
         float tmin;
-        const bool pass = at && slab(o, inv, q[0], q[1], q[2], q[4], q[5], q[6], tmin) && !(tmin > tHit);
+        const bool box = slab(o, inv, q[0], q[1], q[2], q[4], q[5], q[6], tmin);
+        const bool pass = at & box & !(tmin > tHit);
         const int count = __float_as_int(q[7]), skip = __float_as_int(q[8]);
         if (count > 0) {
             if (rz_ballot(pass) != 0ull) {
@@ -521,10 +524,12 @@ __device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitR
             }
             if (at) idx = skip;
             pos = skip;
-        } else {
-            const bool down = pass && count < 0;    // count == 0: the host builder's empty root, or a node the shader's stack could not expand
-            if (at) idx = down ? pos + 1 : skip;
-            pos = rz_ballot(down) != 0ull ? pos + 1 : skip;
+        } else if (count < 0) {                     // internal: the right child is the next record
+            if (at) idx = pass ? pos + 1 : skip;
+            pos = rz_ballot(pass) != 0ull ? pos + 1 : skip;
+        } else {                                    // count == 0: the host builder's empty root, or a node the shader's stack could not expand
+            if (at) idx = skip;
+            pos = skip;
         }
     }
     if (bestTri < 0) return false;
