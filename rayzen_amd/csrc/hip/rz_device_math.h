@@ -73,6 +73,29 @@ __device__ __forceinline__ v3 xform_normal(const float* m, v3 v) {
                (m[8] * v.x + m[9] * v.y) + m[10] * v.z);
 }
 
+// ---- reciprocals ------------------------------------------------------------
+// 1.0f / x must be the correctly rounded IEEE quotient (section "pinned numerics" of DESIGN.md); hipcc expands it to 11
+// instructions (two v_div_scale, v_rcp, five FMA-class steps, v_div_fmas, v_div_fixup: ~31 issue cycles).  For
+// 2^-126 <= |x| <= 2^126 -- x and 1/x both normal -- ONE Newton step on the hardware's 1-ulp v_rcp_f32 already rounds
+// correctly: checked for every one of the 2^32 bit patterns (profiles/scripts/rcp_exhaustive.hip; tests/test_rcp_gpu.py
+// repeats the sweep on the GPU the suite runs on), so the callers use it when a wave-level range test passes and the
+// full division otherwise.  Outside that range the short form is wrong (denormal quotients are rounded twice).
+__device__ __forceinline__ float rcp_mid(float x) {
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+__device__ __forceinline__ bool rcp_mid_ok(float x) {       // false for NaN, zero, denormals, infinities too
+    const float a = __builtin_fabsf(x);
+    return (a >= 0x1p-126f) & (a <= 0x1p126f);
+}
+// (1/x, 1/y, 1/z) of a ray direction
+__device__ __forceinline__ v3 rcp3(v3 d) {
+    const bool ok = rcp_mid_ok(d.x) & rcp_mid_ok(d.y) & rcp_mid_ok(d.z);
+    if (rz_ballot(!ok) == 0ull) return mk3(rcp_mid(d.x), rcp_mid(d.y), rcp_mid(d.z));
+    return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+}
+
 // ---- sin / cos / acos -----------------------------------------------------
 // A binary64 literal cannot be an inline operand on gfx950, so hipcc materialises each one in a register pair -- and,
 // left alone, hoists all ~24 of them out of the sample loop and keeps them in VGPRs across the whole BVH walk

@@ -171,7 +171,7 @@ __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
     a.light_fetches += b.light_fetches; a.samples += b.samples;
 #ifdef RZ_PROF
     for (int k = 0; k < 16; ++k) a.p[k] += b.p[k];
-    for (int k = 0; k < 4; ++k) a.t[k] += b.t[k];
+    for (int k = 0; k < 10; ++k) a.t[k] += b.t[k];
 #endif
 }
 
@@ -442,7 +442,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
     if (COUNT) {
         unsigned long long* pr = reinterpret_cast<unsigned long long*>(K.counters + 1);
         for (int k = 0; k < 16; ++k) if (c.p[k]) atomicAdd(&pr[k], (unsigned long long)c.p[k]);
-        if (lane == 0) { atomicAdd(&pr[17], tTrace); atomicAdd(&pr[18], tAdv); atomicAdd(&pr[19], c.t[0]); atomicAdd(&pr[20], c.t[1]); atomicAdd(&pr[21], c.t[2]); }
+        if (lane == 0) { atomicAdd(&pr[17], tTrace); atomicAdd(&pr[18], tAdv); atomicAdd(&pr[19], c.t[0]); atomicAdd(&pr[20], c.t[1]); atomicAdd(&pr[21], c.t[2]); for (int k = 3; k < 10; ++k) atomicAdd(&pr[19 + k], c.t[k]); }
     }
 #endif
     if (COUNT) {

@@ -18,6 +18,14 @@
 
 namespace rz {
 
+#ifdef RZ_PROF
+#define RZ_T0() const unsigned long long rzt0_ = __builtin_amdgcn_s_memtime()
+#define RZ_T1(c, k) (c).t[k] += __builtin_amdgcn_s_memtime() - rzt0_
+#else
+#define RZ_T0() do { } while (0)
+#define RZ_T1(c, k) do { } while (0)
+#endif
+
 enum : int { MODE_SEGMENT = 0, MODE_SHADOW = 1, MODE_DONE = 2 };
 
 struct Path {
@@ -118,6 +126,7 @@ __device__ __forceinline__ v3 random_hemisphere_direction(v3 normal, v2 seed) {
 // `transparency > 0` branch of the shader is dead and is compiled out (fewer live registers, less code).
 template <bool COUNT, bool GLASS>
 __device__ __forceinline__ void start_light(const KParams& K, Path& P, Tally& c) {
+    RZ_T0();
     const DevLight L = K.lights[P.li];
     const DevMaterial M = K.materials[P.hmat];
     if (COUNT) c.light_fetches += 1;
@@ -137,6 +146,7 @@ __device__ __forceinline__ void start_light(const KParams& K, Path& P, Tally& c)
     P.traveled = 0.0f;
     P.iter = 0;
     P.mode = MODE_SHADOW;
+    RZ_T1(c, 5);
 }
 
 // The light P.li is visible with P.vis: add its term (FS:589-607 / FS:636-659).
@@ -197,7 +207,8 @@ __device__ __forceinline__ void shade_light(const KParams& K, Path& P) {
 
 // FS:720-769: choose the next direction at the parked surface point and move on.
 template <bool GLASS>
-__device__ __forceinline__ void scatter(const KParams& K, Path& P) {
+__device__ __forceinline__ void scatter(const KParams& K, Path& P, Tally& c) {
+    RZ_T0();
     const DevMaterial M = K.materials[P.hmat];
     const float fb2 = (float)(P.bounce * P.bounce), fb = (float)P.bounce;
     v2 tempseed;
@@ -234,7 +245,15 @@ __device__ __forceinline__ void scatter(const KParams& K, Path& P) {
             dir = reflect_ray(dir, hitNormal);
             P.throughput = P.throughput * 0.95f;
         } else {
-            dir = random_hemisphere_direction(hitNormal, tempseed);
+            {
+#ifdef RZ_PROF
+                const unsigned long long th0_ = __builtin_amdgcn_s_memtime();
+#endif
+                dir = random_hemisphere_direction(hitNormal, tempseed);
+#ifdef RZ_PROF
+                c.t[8] += __builtin_amdgcn_s_memtime() - th0_;
+#endif
+            }
             P.throughput = P.throughput * (mk3(M.albedo[0], M.albedo[1], M.albedo[2]) * 0.4f);
         }
     }
@@ -244,19 +263,20 @@ __device__ __forceinline__ void scatter(const KParams& K, Path& P) {
     P.mode = MODE_SEGMENT;
     if (P.bounce > 2) {     // Russian roulette with the SAME random number (FS:764-769)
         const float p = fmax_(P.throughput.x, fmax_(P.throughput.y, P.throughput.z));
-        if (randVal > p) { end_sample(P); return; }
+        if (randVal > p) { end_sample(P); RZ_T1(c, 7); return; }
         P.throughput = P.throughput / p;
     }
     P.bounce += 1;
     if (P.bounce >= K.maxBounces) end_sample(P);
+    RZ_T1(c, 7);
 }
 
 // Lighting of the parked point is complete (or there are no lights): FS:717, then scatter.
 template <bool GLASS>
-__device__ __forceinline__ void finish_lighting(const KParams& K, Path& P) {
+__device__ __forceinline__ void finish_lighting(const KParams& K, Path& P, Tally& c) {
     P.addLight = P.throughput * P.lacc;
     P.color = P.color + P.addLight;
-    scatter<GLASS>(K, P);
+    scatter<GLASS>(K, P, c);
 }
 
 // Advance a path by the result of the closest-hit query of its current ray.
@@ -264,11 +284,13 @@ template <bool COUNT, bool GLASS = true>
 __device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, const HitRec& h, Tally& c) {
     if (P.mode == MODE_SEGMENT) {
         if (!found) {   // FS:705-711
+            RZ_T0();
             const float t = 0.5f * (normalize(P.d).y + 1.0f);
             const v3 sky = mk3(mix_(0.15f, 0.5f, t), mix_(0.25f, 0.7f, t), mix_(0.45f, 1.0f, t));
             P.addSky = P.throughput * sky;
             P.color = P.color + P.addSky;
             end_sample(P);
+            RZ_T1(c, 3);
             return;
         }
         if (COUNT) c.materials += 1;        // FS:713
@@ -280,10 +302,10 @@ __device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, c
                          : mk3(0.05f * M.albedo[0], 0.05f * M.albedo[1], 0.05f * M.albedo[2]);
             P.li = 0;
             if (K.nLights > 0) { start_light<COUNT, GLASS>(K, P, c); return; }
-            finish_lighting<GLASS>(K, P);
+            finish_lighting<GLASS>(K, P, c);
             return;
         }
-        scatter<GLASS>(K, P);
+        scatter<GLASS>(K, P, c);
         return;
     }
     // MODE_SHADOW: the body of one iteration of FS:511-526
@@ -305,10 +327,10 @@ __device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, c
         if (P.iter < 32 && P.vis > 0.05f) return;   // next iteration: trace again
         lit = P.vis > 0.05f;                         // FS:527
     }
-    if (lit) shade_light<GLASS>(K, P);
+    if (lit) { RZ_T0(); shade_light<GLASS>(K, P); RZ_T1(c, 6); }
     P.li += 1;
     if (P.li < K.nLights) { start_light<COUNT, GLASS>(K, P, c); return; }
-    finish_lighting<GLASS>(K, P);
+    finish_lighting<GLASS>(K, P, c);
 }
 
 }  // namespace rz

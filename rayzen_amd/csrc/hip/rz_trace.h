@@ -43,7 +43,7 @@ struct Tally {          // per-thread counts of the REFERENCE algorithm's memory
         samples;
 #ifdef RZ_PROF          // diagnostic build only: where do the lanes of a wave spend their iterations?
     unsigned p[16];
-    unsigned long long t[4];    // wave cycles (s_memtime): [0] descend loops, [1] leaf phases, [2] whole BLAS walks
+    unsigned long long t[10];   // wave cycles (s_memtime): [0] descend loops, [1] leaf phases, [2] whole BLAS walks; rz_path.h advance(): [3] sky, [4] hit bookkeeping, [5] start_light, [6] shade_light, [7] scatter, [8] of it the hemisphere direction, [9] shadow-step bookkeeping
 #endif
 };
 #ifdef RZ_PROF
@@ -191,7 +191,11 @@ __device__ __forceinline__ bool slab_finish(f32x2 tx, f32x2 ty, f32x2 tz, float&
 __device__ __forceinline__ bool moller_trumbore(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float& t) {
     v3 h = cross(d, e2);
     float a = dot(e1, h);
-    float f = 1.0f / a;
+    // FS:398.  A lane whose |a| < 0.0001 fails the shader's first test whatever f is, so only |a| <= 2^126 has to hold
+    // for the short reciprocal (NaN and infinities fail the comparison and take the division).
+    float f;
+    if (rz_ballot(!(__builtin_fabsf(a) <= 0x1p126f)) == 0ull) f = rcp_mid(a);
+    else f = 1.0f / a;
     v3 s = o - v0;
     float u = f * dot(s, h);
     // (every comparison is evaluated for every lane and the results are combined as lane masks: written as
@@ -411,7 +415,7 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
 template <bool COUNT, bool OVF>
 __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance* __restrict__ I, v3 lo, v3 ld,
                                              float& tLocOut, const BlasStackT<OVF>& bstk, Tally& c) {
-    const v3 inv = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
+    const v3 inv = rcp3(ld);
     if (COUNT) c.blas_nodes += 1;            // the shader pops the root
     // (I is wave-uniform: the instance's root box, root reference and bases come through the scalar cache)
     const f32x8 r0 = sload8(I->rootMin);     // rootMin[3], rootEnc, rootMax[3], pairBase
@@ -478,7 +482,7 @@ __device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitR
     int bestTri = -1, bestInst = -1;
     v3 bestP = mk3(0.0f, 0.0f, 0.0f);
     if (COUNT) c.traversals += 1;
-    const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const v3 inv = rcp3(d);
     int idx = 0;                                    // the position this lane visits next
     const int nDfs = K.nTlasDfs;
     for (int pos = 0; pos < nDfs;) {                // wave-uniform; pos strictly grows (skip > pos by construction, checked on the host)
