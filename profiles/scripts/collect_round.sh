@@ -3,11 +3,11 @@
 #   kernel trace + stats of bench.py, PMC passes for C2 / C4 / C5 frames, the issue microbenchmark and its own counters.
 set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/prof_r02; mkdir -p $O
+O=gpurun_out/prof_r02b; mkdir -p $O
 python3 bench.py --steps 10 --warmup 2 --cpu-full-frame > $O/bench_c2.json 2> $O/bench_c2.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c2 -o run -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 1 > $O/kt_c2.log 2>&1
 python3 profiles/scripts/pmc_collect.py $O/pmc_c2.json rz_render_samples --workload 1920,1080,64,4,76 -- python3 profiles/scripts/one_frame.py c2 > $O/pmc_c2.log 2>&1
-for c in c4 c5; do
+for c in c4 c5full; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$c -o run -- python3 profiles/scripts/one_frame.py $c > $O/kt_$c.log 2>&1
   python3 profiles/scripts/pmc_collect.py $O/pmc_$c.json rz_render_samples -- python3 profiles/scripts/one_frame.py $c > $O/pmc_$c.log 2>&1
 done

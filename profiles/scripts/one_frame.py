@@ -1,5 +1,5 @@
 """Two frames of one BASELINE configuration with the default kernel (for rocprofv3 passes that should not pay for
-bench.py's extras):  one_frame.py [c2|c4|c5]   (c2 is the bench workload; c5 at 32 spp keeps counter passes short)."""
+bench.py's extras):  one_frame.py [c2|c4|c5|c5full]   (c2 is the bench workload; c5 = C5 at 32 spp, c5full at its 128 spp)."""
 import os
 import sys
 
@@ -16,6 +16,9 @@ elif which == "c4":
     sc = S.instanced_scene(n=76, count=16, aspect=W / H)
 elif which == "c5":
     W, H, SPP, B = 3840, 2160, 32, 8
+    sc = S.stress_scene(n=289, aspect=W / H)
+elif which == "c5full":            # BASELINE configs[4] as stated: 128 spp (the persistent, compacting launch; c5 at 32 spp is one workgroup per pixel pair)
+    W, H, SPP, B = 3840, 2160, 128, 8
     sc = S.stress_scene(n=289, aspect=W / H)
 else:
     raise SystemExit(which)

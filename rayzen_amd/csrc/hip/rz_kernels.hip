@@ -41,7 +41,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    // LDS: per wave, [blasStackCap][64] uint2 then [tlasStackCap][64] int
+    // LDS: per wave, [blasStackCap][64] uint2 (tlasStackCap is 0: the TLAS walk keeps no stack)
     const size_t perWave = (size_t)K.blasStackCap * 64 * sizeof(uint2) + (size_t)K.tlasStackCap * 64 * sizeof(int);
     unsigned char* base = lds_raw + perWave * wave;
     const BlasStackT<false> bstk{reinterpret_cast<uint2*>(base) + lane, nullptr, K.blasStackCap};

@@ -21,6 +21,8 @@
 //    are conflict-free at any mix of depths (ds_write_b64 / ds_read_b64,
 //    2 x 32-lane groups).  Capacity = the deepest BLAS of the scene, known on
 //    the host at upload time.
+//  * TLAS: no stack at all -- the nodes are laid out in the shader's pop order with skip positions and the wave walks
+//    that list with one scalar cursor (trace_closest below).
 //  * leaves index triangles gathered into leaf order (DevTri, 3 x 16-B loads,
 //    no index indirection); only (t, triangle id) are tracked while
 //    traversing -- hit point, normal and material are pure functions of the
@@ -31,9 +33,6 @@
 
 namespace rz {
 
-#ifndef RZ_TLAS_MIN_LANES
-#define RZ_TLAS_MIN_LANES 1     // leave the TLAS pop loop when fewer lanes than this are still popping (the rest hold a leaf or are done): C4 (17 instances, 4 pixels per wave) 12.24 ms entering at once, 11.82 / 11.15 / 10.83 ms at 32 / 8 / 1; C2 indifferent
-#endif
 #ifndef RZ_DESCEND_MIN_LANES
 #define RZ_DESCEND_MIN_LANES 4   // leave the descend loop when fewer lanes than this still have an internal node (lane=sample kernel on C2: 1 -> 17.6 ms, 2 -> 17.4, 3..6 -> 17.15-17.2, 8 -> 17.3, 12 -> 17.4)
 #endif
