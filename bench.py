@@ -34,7 +34,7 @@ SIMDS = 256 * 4                 # 256 CUs x 4 SIMD-32
 MAX_CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md "Max clock"
 ISSUE_CYCLES_PER_INST = 2.0     # a SIMD issues at most one wave64 instruction per 2 cycles (profiles/r02_valu_issue)
 ISSUE_PEAK_GINST = SIMDS * MAX_CLOCK_HZ / ISSUE_CYCLES_PER_INST / 1e9
-PMC_JSON = os.path.join(ROOT, "profiles", "r02_c2_kernel", "pmc_rz_render_samples.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r02b_c2_kernel", "pmc_rz_render_samples.json")
 INST_COUNTERS = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
                  "SQ_INSTS_VMEM_WR", "SQ_INSTS_BRANCH")
 
