@@ -9,6 +9,7 @@ from rayzen_amd.renderer import Renderer, frame_params
 
 W, H, SPP, B = 1920, 1080, 64, 4
 which = sys.argv[1] if len(sys.argv) > 1 else "c2"
+NRANKS = int(sys.argv[2]) if len(sys.argv) > 2 else 1      # render rank 0's share of an NRANKS-way tile split
 if which == "c2":
     sc = S.bunny_scene(n=76, aspect=W / H)
 elif which == "c4":
@@ -18,7 +19,7 @@ elif which == "c5":
     sc = S.stress_scene(n=289, aspect=W / H)
 r = Renderer(0)
 r.upload_scene(sc)
-r.set_frame(frame_params(sc.camera, W, H, len(sc.lights), B, SPP))
+r.set_frame(frame_params(sc.camera, W, H, len(sc.lights), B, SPP, 0, 0, NRANKS))
 r.render()
 r.sync()
 c = r.render_counted()

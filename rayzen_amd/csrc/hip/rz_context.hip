@@ -112,6 +112,7 @@ struct rz_ctx {
     int ringCount = 0;      // launches recorded since the history was last drained (<= kRing)
     bool timed = false;
     int lastLaunches = 0;
+    long long lastGrid = 0;         // workgroups of the last render launch (RZ_PROF: how many wave-log entries are valid)
     std::string err;
 
     // host copies of the caller's arrays (the re-layout needs them; rz_update patches them)
@@ -664,6 +665,7 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     if (K.nSlots > 0) launch_render_samples(K, counted, c->sceneHasTransparency, c->stream);
     RZ_HIP(c, hipEventRecord(c->evStop[evSlot], c->stream));
     c->lastLaunches = K.nSlots > 0 ? 1 : 0;
+    c->lastGrid = plan.grid;
     return RZ_OK;
 }
 
@@ -747,7 +749,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
 #ifdef RZ_PROF
         unsigned long long pr[32];
         RZ_HIP(c, hipMemcpy(pr, static_cast<char*>(c->dCounters.p) + sizeof(DevCounters), sizeof pr, hipMemcpyDeviceToHost));
-        dump_wave_log(K.nLocalTiles);
+        dump_wave_log(use_samples(c) ? (int)std::min<long long>(c->lastGrid, 1 << 17) : K.nLocalTiles);
         static const char* namesPx[] = {"blas loop iter", "leaf branch", "triangle test", "internal branch", "tlas pop", "instance enter", "outer iter", "uniform pair"};
         const char** names = namesPx;
         for (int k = 0; k < 8; ++k)

@@ -674,6 +674,10 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
 template <bool COUNT, bool GLASS, bool OVF, bool COMPACT>
 __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES_MIN_WAVES) void rz_render_samples(const KParams K, const unsigned nGroups, const unsigned perClaim) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+#ifdef RZ_PROF
+    const unsigned long long wl_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned wl_claims = 0;
+#endif
     if (perClaim == 0) {                        // one workgroup per pixel group (small launches, spp < 64)
         render_samples_group<COUNT, GLASS, OVF>(K, blockIdx.x, lds_raw);
         return;
@@ -683,6 +687,9 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
         if ((threadIdx.x & 63) == 0) base = atomicAdd(K.groupCounter, perClaim);
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= nGroups) break;             // every wave of the grid reaches this: the counter only grows
+#ifdef RZ_PROF
+        ++wl_claims;
+#endif
         const unsigned end = base + perClaim < nGroups ? base + perClaim : nGroups;
         if constexpr (COMPACT && !GLASS) {
             render_claim_compact<COUNT, OVF>(K, base, end, lds_raw);
@@ -690,6 +697,13 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
             for (unsigned wb = base; wb < end; ++wb) render_samples_group<COUNT, GLASS, OVF>(K, wb, lds_raw);
         }
     }
+#ifdef RZ_PROF
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < (1u << 17)) {      // the persistent wave's lifetime and the claims it served
+        rz_wave_log[blockIdx.x][0] = wl_t0;
+        rz_wave_log[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+        rz_wave_log[blockIdx.x][2] = wl_claims;
+    }
+#endif
 }
 
 // FS:772-773 + 8-bit quantisation: rgba8 = round(clamp(sum / n, 0, 1) * 255), a = 255.
@@ -736,6 +750,16 @@ void dump_wave_log(int nWaves) {
         double a = (double)(h[3 * i] - t0) * 1e-5, b = (double)(h[3 * i + 1] - t0) * 1e-5;
         for (int s = 0; s < NS; ++s) { double lo = span * s / NS, hi = span * (s + 1) / NS; double o = std::min(b, hi) - std::max(a, lo); if (o > 0) res[s] += o / (hi - lo); }
     }
+    {   // third word of the log: claims served (persistent sample kernel) / hardware id (pixel kernel)
+        std::vector<unsigned long long> w3(nWaves);
+        for (int i = 0; i < nWaves; ++i) w3[i] = h[3 * i + 2];
+        std::sort(w3.begin(), w3.end());
+        fprintf(stderr, "[rz_prof] third log word per wave (claims served): min %llu  p10 %llu  med %llu  p90 %llu  max %llu\n", w3[0], w3[nWaves / 10], w3[nWaves / 2], w3[nWaves * 9 / 10], w3[nWaves - 1]);
+        std::vector<double> ends(nWaves);       // a long tail of ends = the launch waits for the last claims handed out
+        for (int i = 0; i < nWaves; ++i) ends[i] = (double)(h[3 * i + 1] - t0) * 1e-5;
+        std::sort(ends.begin(), ends.end());
+        fprintf(stderr, "[rz_prof] wave END times (ms from the first start): p1 %.3f  p10 %.3f  med %.3f  p90 %.3f  p99 %.3f  max %.3f\n", ends[nWaves / 100], ends[nWaves / 10], ends[nWaves / 2], ends[nWaves * 9 / 10], ends[nWaves * 99 / 100], ends[nWaves - 1]);
+    }
     fprintf(stderr, "[rz_prof] resident waves per 5%% time slice:");
     for (int s = 0; s < NS; ++s) fprintf(stderr, " %.0f", res[s]);
     fprintf(stderr, "\n");
@@ -756,11 +780,20 @@ SamplesPlan plan_render_samples(int spp, int nSlots, bool glass) {
         nCU = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                   ? prop.multiProcessorCount : 256;
     }
-    p.perClaim = (spp >= 64 && p.groups >= (long long)nCU * RZ_PERSIST_WAVES_PER_CU * 16) ? RZ_GROUPS_PER_CLAIM : 0;
+    const int nBatches = (spp + 63) / 64;
+    // A claim is sized in WORK, RZ_GROUPS_PER_CLAIM (pixel, 64-sample batch) units: 8 pixels at 64 spp, 2 at 256, 1 from
+    // 512 on.  (Sized in pixels, one rank's share of an 8-GPU weak-scaling frame -- 1/8 of the tiles at 512 spp -- was
+    // 4 050 claims for 4 096 waves: 21.9 ms for the work of an 11.3-ms frame, 12.2 ms now.)
+    // Small launches (under 3/4 M units: a 1/4 or 1/8 share of a 1080p frame at 64 spp) take half-size claims: a claim in the
+    // middle of the bunny lasts ten times the average and the launch cannot end before the last such claim has run -- with
+    // 8-unit claims a 1/8-frame launch took 2.80 ms for 1.41 ms of work, with 4-unit claims 1.93 (rank_share.py; the
+    // RZ_PROF wave log shows the resident waves draining over the second half of such a launch).  A full frame keeps 8:
+    // its claims compact better (11.3 against 12.3 ms; a half frame 5.87 against 6.15) and its tail is 0.3 ms.
+    const int claimUnits = p.groups * nBatches >= (3ll << 18) ? RZ_GROUPS_PER_CLAIM : std::max(1, RZ_GROUPS_PER_CLAIM / 2);
+    p.perClaim = (spp >= 64 && p.groups >= (long long)nCU * RZ_PERSIST_WAVES_PER_CU * 16) ? std::max(1, claimUnits / nBatches) : 0;
     if (const char* e = std::getenv("RZ_GROUPS_PER_CLAIM")) p.perClaim = std::max(0, std::atoi(e));      // tuning aid
     // ray compaction across the units of a claim (render_claim_compact): opaque scenes, persistent launches, and a claim
     // must hold at most RZ_CLAIM_UNITS (pixel, 64-sample batch) units
-    const int nBatches = (spp + 63) / 64;
     bool compact = RZ_COMPACT_DEFAULT != 0;
     if (const char* e = std::getenv("RZ_COMPACT")) compact = std::atoi(e) != 0;                            // A/B aid
     // (measured: C2, 64 spp, 14.29 -> 13.28 ms; 128 spp C5 144.2 -> 143.0; at 256 spp a claim is 2 pixels and the gain is gone)
