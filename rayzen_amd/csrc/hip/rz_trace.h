@@ -484,7 +484,10 @@ __device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitR
     const v3 inv = rcp3(d);
     int idx = 0;                                    // the position this lane visits next
     const int nDfs = K.nTlasDfs;
-    for (int pos = 0; pos < nDfs;) {                // wave-uniform; pos strictly grows (skip > pos by construction, checked on the host)
+    // (pos strictly grows -- a skip position lies behind its node, by construction on the host and on the device -- so the
+    //  list is walked in at most nDfs steps; `step` is the backstop against a list that says otherwise: a wave that never
+    //  leaves this loop takes the device with it)
+    for (int pos = 0, step = 0; pos < nDfs && step < nDfs; ++step) {
         const f32x16 q = sload16(K.tlasDfs + pos);
         const bool at = idx == pos;
         RZ_SITE(c, 4);
