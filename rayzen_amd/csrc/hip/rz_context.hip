@@ -40,6 +40,7 @@ SamplesPlan plan_render_samples(int spp, int nSlots, bool glass);
 size_t samples_lds_extra(bool glass, bool compact);
 void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream_t stream);
 void launch_resolve(const float4* accum, uchar4* out, int n, hipStream_t stream);
+int compute_hemi0(float out[3], hipStream_t stream);
 struct RelayoutView {        // rz_relayout.hip
     int nodeOff, triOff, gTriOff; int pairBase, triBase; int nPairs, nSlots, depth, rootEnc, empty; float rootMin[3], rootMax[3];
 };
@@ -112,6 +113,7 @@ struct rz_ctx {
     int ringCount = 0;      // launches recorded since the history was last drained (<= kRing)
     bool timed = false;
     int lastLaunches = 0;
+    float hemi0[3] = {0.0f, 0.0f, 0.0f};   // KParams::hemi0, computed at rz_create
     long long lastGrid = 0;         // workgroups of the last render launch (RZ_PROF: how many wave-log entries are valid)
     std::string err;
 
@@ -711,6 +713,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     std::memcpy(K.invView, f.inv_view, 64);
     std::memcpy(K.invProj, f.inv_proj, 64);
     std::memcpy(K.camPos, f.cam_pos, 12);
+    std::memcpy(K.hemi0, c->hemi0, 12);
     const size_t perWave = (size_t)K.blasStackCap * 512 + (size_t)K.tlasStackCap * 256 + 4864;
     if (perWave * 4 > 160 * 1024)   // sized for the largest (4-wave) workgroup
         return fail(c, RZ_ERR_BAD_SCENE, "BLAS depth %d needs %zu B of LDS stack per wave; the limit is %d", c->maxBlasDepth, perWave, 40 * 1024);
@@ -806,6 +809,12 @@ rz_ctx* rz_create(int device, unsigned flags) {
         return nullptr;
     }
     c->stream = c->ownStream;
+    const int hrc = compute_hemi0(c->hemi0, c->stream);
+    if (hrc != 0) {
+        fail(nullptr, RZ_ERR_HIP, "cannot run the set-up kernel on device %d: %s", device, hipGetErrorString((hipError_t)(-hrc)));
+        rz_destroy(c);
+        return nullptr;
+    }
     return c;
 }
 

@@ -832,6 +832,24 @@ void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream
 #undef RZ_LAUNCH_SAMPLES
 }
 
+// The local hemisphere direction of a zero seed (rz_path.h: random_hemisphere_direction), by the kernels' own arithmetic.
+__global__ void rz_hemi0_kernel(float* out) {
+    v2 z; z.x = 0.0f; z.y = 0.0f;
+    const v3 d = hemisphere_local(z);
+    out[0] = d.x; out[1] = d.y; out[2] = d.z;
+}
+int compute_hemi0(float out[3], hipStream_t stream) {
+    float* d = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), 3 * sizeof(float));
+    if (e != hipSuccess) return -(int)e;
+    hipLaunchKernelGGL(rz_hemi0_kernel, dim3(1), dim3(1), 0, stream, d);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, 3 * sizeof(float), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d);
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
 void launch_resolve(const float4* accum, uchar4* out, int n, hipStream_t stream) {
     hipLaunchKernelGGL(rz_resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, accum, out, n);
 }

@@ -103,8 +103,8 @@ __device__ __forceinline__ bool refract_dir(v3 incident, v3 normal, float eta, v
     refr = normalize(incident * eta + normal * w);
     return true;
 }
-// FS:192-202
-__device__ __forceinline__ v3 random_hemisphere_direction(v3 normal, v2 seed) {
+// FS:192-202.  The first half -- two hash numbers, acos, two sin/cos pairs in binary64 -- depends on the seed alone.
+__device__ __forceinline__ v3 hemisphere_local(v2 seed) {
     const float u = rand_(seed);
     v2 s1; s1.x = seed.x + 1.0f; s1.y = seed.y + 1.0f;
     const float v = rand_(s1);
@@ -113,11 +113,23 @@ __device__ __forceinline__ v3 random_hemisphere_direction(v3 normal, v2 seed) {
     float st, ct, sp, cp;
     sincos_(theta, st, ct);
     sincos_(phi, sp, cp);
-    const v3 dir = mk3(st * cp, st * sp, ct);
+    return mk3(st * cp, st * sp, ct);
+}
+__device__ __forceinline__ v3 hemisphere_world(v3 normal, v3 dir) {
     const v3 up = (__builtin_fabsf(normal.y) < 0.99f) ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
     const v3 tangent = normalize(cross(up, normal));
     const v3 bitangent = cross(normal, tangent);
     return normalize((tangent * dir.x + bitangent * dir.y) + normal * dir.z);
+}
+// The shader seeds this with tempseed = seed * float(bounce * bounce) * 12793.46 + float(bounce) * 1423.34 (FS:696): at
+// bounce 0 that is (+0, +0) for every pixel and every sample (seed > 0), so every first scatter draws the SAME local
+// direction.  It is computed once per context by rz_hemi0_kernel with this very function (K.hemi0) and the wave skips
+// the five binary64 evaluations -- 1.4 % of the C2 frame -- when all its lanes carry the zero seed (compared by bit pattern).
+__device__ __forceinline__ v3 random_hemisphere_direction(const KParams& K, v3 normal, v2 seed) {
+    const bool zero = __float_as_uint(seed.x) == 0u && __float_as_uint(seed.y) == 0u;
+    v3 dir = mk3(K.hemi0[0], K.hemi0[1], K.hemi0[2]);
+    if (!zero) dir = hemisphere_local(seed);
+    return hemisphere_world(normal, dir);
 }
 
 // Set up the shadow query of light P.li for the parked surface point
@@ -249,7 +261,7 @@ __device__ __forceinline__ void scatter(const KParams& K, Path& P, Tally& c) {
 #ifdef RZ_PROF
                 const unsigned long long th0_ = __builtin_amdgcn_s_memtime();
 #endif
-                dir = random_hemisphere_direction(hitNormal, tempseed);
+                dir = random_hemisphere_direction(K, hitNormal, tempseed);
 #ifdef RZ_PROF
                 c.t[8] += __builtin_amdgcn_s_memtime() - th0_;
 #endif

@@ -117,6 +117,7 @@ struct KParams {
     uint2* blasOvf;         // [resident wave][blasOvfCap][64 lanes]
     float* claimScratch;    // compacting launches (rz_kernels.hip: render_claim_compact): per resident wave, addends + survivor pool
     uint32_t claimStride;   // dwords from one resident wave's scratch to the next (>= RZ_CLAIM_SCRATCH_DWORDS)
+    float hemi0[3];         // rz_path.h: hemisphere_local((+0, +0)), the local direction of every bounce-0 scatter (rz_hemi0_kernel, once per context)
 };
 
 // Arguments of the device TLAS rebuild (rz_tlas_device.hip: rz_tlas_refit; filled in by rz_context.hip).
