@@ -49,6 +49,7 @@ int relayout_view_device(const rz_bvh_node* nodes, long long nNodes, const int32
                          long long nTris, const rz_material* mats, int nMat, const rz_bvh_node& hostRoot, RelayoutView& V,
                          DevPair* pairs, long long pairCap, DevTri* trisOut, long long triCap, void* workspace, size_t workspaceBytes,
                          int* pinned, unsigned* transparentOut, hipStream_t s);
+int tri_normals_device(const DevTri* tris, long long n, DevTriN* out, hipStream_t s);
 int relayout_check_materials_device(const DevTri* tris, long long n, const rz_material* mats, int nMat, void* workspace, int* pinned,
                                     unsigned* transparentOut, int* detail, hipStream_t s);
 struct PresentParams {      // rz_present.hip
@@ -114,6 +115,7 @@ struct rz_ctx {
     bool timed = false;
     int lastLaunches = 0;
     float hemi0[3] = {0.0f, 0.0f, 0.0f};   // KParams::hemi0, computed at rz_create
+    long long triNValid = -1;       // triangles dTriN holds normals for (-1: none; reset with the geometry)
     long long lastGrid = 0;         // workgroups of the last render launch (RZ_PROF: how many wave-log entries are valid)
     std::string err;
 
@@ -134,7 +136,7 @@ struct rz_ctx {
     rz_frame_params frame{};
     DevBuf ownAccum, dIor;
     // device-side dynamic update (rz_update_transforms)
-    DevBuf dXforms, dInstRef, dTlasScratch, dProjBoxes, dBuildWs, dTlasDfs;
+    DevBuf dXforms, dInstRef, dTlasScratch, dProjBoxes, dBuildWs, dTlasDfs, dTriN;
     int nTlasDfs = 0;               // pop positions of the TLAS (rz_trace.h: trace_closest)
     int* tlasHostCounts = nullptr;      // pinned: node count, index count, depth
     bool deviceOwnsTlas = false;        // instances + TLAS on the device are newer than the host copies
@@ -472,6 +474,7 @@ int finalize_body(rz_ctx* c) {
         if (nodesNow >= ((size_t)1 << 27))
             return fail(c, RZ_ERR_BAD_SCENE, "BLAS node array holds %zu nodes; the limit is %zu", nodesNow, ((size_t)1 << 27) - 1);
         c->views.clear(); c->hPairs.clear(); c->hTris.clear(); c->instDirty = true;
+        c->triNValid = -1;
         c->devPairsUsed = c->devTrisUsed = 0; c->devTransparent = 0;
         c->layoutOnDevice = !host_relayout_forced(c);
         if (c->layoutOnDevice) { int rc = prepare_device_relayout(c); if (rc != RZ_OK) return rc; }
@@ -495,14 +498,14 @@ int finalize_body(rz_ctx* c) {
                     rc = device_view(c, inst[i].blasNodeOffset, inst[i].blasTriOffset, inst[i].globalTriOffset, V);
                     if (rc == 1) {          // start over on the host
                         c->layoutOnDevice = false;
-                        c->views.clear(); c->hPairs.clear(); c->hTris.clear();
+                        c->views.clear(); c->hPairs.clear(); c->hTris.clear(); c->triNValid = -1;
                         redo = true;
                         break;
                     }
                 } else {
                     rc = build_view(c, inst[i].blasNodeOffset, inst[i].blasTriOffset, inst[i].globalTriOffset, V);
                 }
-                if (rc != RZ_OK) { c->views.clear(); c->hPairs.clear(); c->hTris.clear(); c->geomDirty = true; return rc; }
+                if (rc != RZ_OK) { c->views.clear(); c->hPairs.clear(); c->hTris.clear(); c->triNValid = -1; c->geomDirty = true; return rc; }
                 c->views.emplace(key, V);
                 grew = true;
             }
@@ -514,6 +517,16 @@ int finalize_body(rz_ctx* c) {
                 if (rc != RZ_OK) return rc;
             }
             break;
+        }
+        {   // per-triangle geometric normals of everything laid out (rz_relayout.hip: rl_tri_normals)
+            const long long nLaid = c->layoutOnDevice ? (long long)c->devTrisUsed : (long long)c->hTris.size();
+            if (nLaid != c->triNValid) {        // (views are only ever appended between two geometry uploads)
+                int rc = ensure(c, c->dTriN, (size_t)std::max<long long>(nLaid, 1) * sizeof(DevTriN));
+                if (rc != RZ_OK) return rc;
+                const int nrc = tri_normals_device(static_cast<const DevTri*>(c->dTris.p), nLaid, static_cast<DevTriN*>(c->dTriN.p), c->stream);
+                if (nrc != 0) return fail(c, RZ_ERR_HIP, "triangle normals: %s", hipGetErrorString((hipError_t)(-nrc)));
+                c->triNValid = nLaid;
+            }
         }
         c->maxBlasDepth = 1;
         for (size_t i = 0; i < nInst; ++i) {
@@ -610,7 +623,7 @@ int finalize(rz_ctx* c) {
     try {
         return finalize_body(c);
     } catch (...) {
-        c->views.clear(); c->hPairs.clear(); c->hTris.clear();
+        c->views.clear(); c->hPairs.clear(); c->hTris.clear(); c->triNValid = -1;
         c->geomDirty = true;
         throw;
     }
@@ -689,6 +702,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     KParams K{};
     K.pairs = static_cast<const DevPair*>(c->dPairs.p);
     K.tris = static_cast<const DevTri*>(c->dTris.p);
+    K.triN = static_cast<const DevTriN*>(c->dTriN.p);
     K.instances = static_cast<const DevInstance*>(c->dInst.p);
     K.tlasDfs = static_cast<const TlasDfs*>(c->dTlasDfs.p);
     K.tlasIndices = static_cast<const int32_t*>(c->dTlasIdx.p);
@@ -823,7 +837,7 @@ void rz_destroy(rz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
-                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs, &c->dTlasDfs, &c->dRawNodes, &c->dRawIdx, &c->dRawTris, &c->dRelayoutWs, &c->dClaimScratch})
+                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs, &c->dTlasDfs, &c->dTriN, &c->dRawNodes, &c->dRawIdx, &c->dRawTris, &c->dRelayoutWs, &c->dClaimScratch})
         b->release();
     if (c->tlasHostCounts) (void)hipHostFree(c->tlasHostCounts);
     if (c->relayoutPinned) (void)hipHostFree(c->relayoutPinned);

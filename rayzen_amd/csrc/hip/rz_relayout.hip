@@ -22,6 +22,7 @@
 #include <cstring>
 
 #include "rayzen_hip.h"
+#include "rz_device_math.h"
 #include "rz_scene_dev.h"
 
 namespace rz {
@@ -136,6 +137,24 @@ int relayout_check_materials_device(const DevTri* tris, long long n, const rz_ma
     if (transparentOut) *transparentOut = (unsigned)pinned[2];
     if (detail) *detail = pinned[1];
     return pinned[0];
+}
+
+// FS:411: the geometric normal of a triangle, normalize(cross(edge1, edge2)), is the same for every ray that hits it; the
+// shader recomputes it per hit.  One pass over the laid-out triangles (either re-layout path) stores it -- the kernels'
+// own cross / normalize on the very edges DevTri holds, so the bits are the ones trace_closest used to compute per hit.
+__global__ void rl_tri_normals(const DevTri* __restrict__ tris, long long n, DevTriN* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DevTri t = tris[i];
+    const v3 ln = normalize(cross(mk3(t.e1x, t.e1y, t.e1z), mk3(t.e2x, t.e2y, t.e2z)));
+    DevTriN o;
+    o.n[0] = ln.x; o.n[1] = ln.y; o.n[2] = ln.z; o.mat = t.mat;
+    out[i] = o;
+}
+int tri_normals_device(const DevTri* tris, long long n, DevTriN* out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(rl_tri_normals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tris, n, out);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
 }
 
 size_t relayout_workspace_bytes(size_t nNodes) {

@@ -50,6 +50,11 @@ struct alignas(16) DevTri {
 };
 static_assert(sizeof(DevTri) == 48, "DevTri is three 16-B loads");
 
+// What the winner of a closest-hit query needs of its triangle -- FS:411's normalize(cross(edge1, edge2)) and the material
+// index -- in one 16-B load (derived from DevTri on the device, rz_relayout.hip: rl_tri_normals).
+struct alignas(16) DevTriN { float n[3]; int32_t mat; };
+static_assert(sizeof(DevTriN) == 16, "DevTriN is one 16-B load");
+
 struct alignas(16) DevInstance {
     float inv[12];      // inverseTransform columns 0..3, rows 0..2: c0.xyz c1.xyz c2.xyz c3.xyz
     float fwd[12];      // transform, same packing
@@ -117,6 +122,7 @@ struct KParams {
     uint2* blasOvf;         // [resident wave][blasOvfCap][64 lanes]
     float* claimScratch;    // compacting launches (rz_kernels.hip: render_claim_compact): per resident wave, addends + survivor pool
     uint32_t claimStride;   // dwords from one resident wave's scratch to the next (>= RZ_CLAIM_SCRATCH_DWORDS)
+    const DevTriN* triN;    // [triangle in leaf order] (rz_trace.h: trace_closest's epilogue)
     float hemi0[3];         // rz_path.h: hemisphere_local((+0, +0)), the local direction of every bounce-0 scatter (rz_hemi0_kernel, once per context)
 };
 

@@ -539,14 +539,13 @@ __device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitR
         }
     }
     if (bestTri < 0) return false;
-    // the winner's normal and material: FS:411-412, 489-491
-    const float4* __restrict__ tp = reinterpret_cast<const float4*>(K.tris + bestTri);
-    const float4 a = tp[0], b = tp[1], cc = tp[2];
-    const v3 ln = normalize(cross(mk3(a.w, b.x, b.y), mk3(b.z, b.w, cc.x)));
+    // the winner's normal and material (FS:411-412, 489-491): the triangle's own normal comes precomputed (DevTriN)
+    const float4 nm = *reinterpret_cast<const float4*>(K.triN + bestTri);
+    const v3 ln = mk3(nm.x, nm.y, nm.z);
     h.t = tHit;
     h.p = bestP;
     h.n = normalize(x34_normal(K.instances[bestInst].inv, ln));
-    h.mat = __float_as_int(cc.y);
+    h.mat = __float_as_int(nm.w);
     h.inst = bestInst;
     return true;
 }
