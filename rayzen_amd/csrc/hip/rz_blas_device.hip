@@ -29,6 +29,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "rayzen_hip.h"
+#include "rz_internal.h"
 
 namespace rz {
 

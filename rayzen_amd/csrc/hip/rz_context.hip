@@ -23,43 +23,8 @@
 #include <vector>
 
 #include "rayzen_hip.h"
-#include "rz_scene_dev.h"
+#include "rz_internal.h"
 
-namespace rz {
-// rz_tlas_device.hip
-void launch_tlas_refit(const TlasWork& W, hipStream_t s);
-// rz_blas_device.hip
-size_t blas_build_workspace_bytes(size_t n);
-int blas_build_device(const rz_triangle* hostTris, size_t n, void* workspace, size_t workspaceBytes, rz_bvh_node* nodes_out,
-                      int32_t* idx_out, int* nNodesOut, int* depthOut, float* ms, hipStream_t s);
-#ifdef RZ_PROF
-void dump_wave_log(int nWaves);
-#endif
-void launch_render_pixels(const KParams& K, bool counted, hipStream_t stream);
-SamplesPlan plan_render_samples(int spp, int nSlots, bool glass);
-size_t samples_lds_extra(bool glass, bool compact);
-void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream_t stream);
-void launch_resolve(const float4* accum, uchar4* out, int n, hipStream_t stream);
-int compute_hemi0(float out[3], hipStream_t stream);
-struct RelayoutView {        // rz_relayout.hip
-    int nodeOff, triOff, gTriOff; int pairBase, triBase; int nPairs, nSlots, depth, rootEnc, empty; float rootMin[3], rootMax[3];
-};
-size_t relayout_workspace_bytes(size_t nNodes);
-int relayout_view_device(const rz_bvh_node* nodes, long long nNodes, const int32_t* idx, long long nIdx, const rz_triangle* tris,
-                         long long nTris, const rz_material* mats, int nMat, const rz_bvh_node& hostRoot, RelayoutView& V,
-                         DevPair* pairs, long long pairCap, DevTri* trisOut, long long triCap, void* workspace, size_t workspaceBytes,
-                         int* pinned, unsigned* transparentOut, hipStream_t s);
-int tri_normals_device(const DevTri* tris, long long n, DevTriN* out, hipStream_t s);
-int relayout_check_materials_device(const DevTri* tris, long long n, const rz_material* mats, int nMat, void* workspace, int* pinned,
-                                    unsigned* transparentOut, int* detail, hipStream_t s);
-struct PresentParams {      // rz_present.hip
-    const float4* accum; uchar4* rgba8; float* rgb; const TlasNode* tlasNodes; const int32_t* tlasIndices;
-    const DevInstance* instances; const DevLight* lights; int width, height; int nTlasNodes, nInstances, nLights;
-    float viewProj[16]; float fps; int showFps, showLights, showBvh, bvhMode; int pathLen;
-    float pathMin[32][3], pathMax[32][3]; float selTransform[16]; void* boxes;
-};
-void launch_present(const PresentParams& P, hipStream_t s);
-}  // namespace rz
 
 using namespace rz;
 
@@ -1249,7 +1214,7 @@ static int present_impl(rz_ctx* c, const rz_present_params* pp, uint8_t* rgba8, 
         const size_t nBoxes = (size_t)P.nTlasNodes + (size_t)P.nInstances + 32;
         rc = ensure(c, c->dProjBoxes, nBoxes * 112);
         if (rc != RZ_OK) return rc;
-        P.boxes = c->dProjBoxes.p;
+        P.boxes = static_cast<ProjBox*>(c->dProjBoxes.p);
     }
     launch_present(P, c->stream);
     RZ_HIP(c, hipGetLastError());

@@ -18,6 +18,7 @@
 
 #include "rayzen_hip.h"
 #include "rz_path.h"
+#include "rz_internal.h"
 
 namespace rz {
 

@@ -8,28 +8,9 @@
 
 #include "rayzen_hip.h"
 #include "rz_device_math.h"
-#include "rz_scene_dev.h"
+#include "rz_internal.h"
 
 namespace rz {
-
-struct PresentParams {
-    const float4* accum;
-    uchar4* rgba8;              // may be null
-    float* rgb;                 // may be null: 3 floats per pixel, the colour before quantisation
-    const TlasNode* tlasNodes;
-    const int32_t* tlasIndices;
-    const DevInstance* instances;
-    const DevLight* lights;
-    int width, height;
-    int nTlasNodes, nInstances, nLights;
-    float viewProj[16];         // projectionMatrix * viewMatrix
-    float fps;
-    int showFps, showLights, showBvh, bvhMode;
-    int pathLen;                // bvhMode 1: nodes on the branch to the selected triangle
-    float pathMin[32][3], pathMax[32][3];   // their object-space boxes
-    float selTransform[16];     // the selected instance's transform
-    struct ProjBox* boxes;      // screen-space corners of every box a pixel may have to draw, projected ONCE
-};
 
 // The 8 projected corners of one box (FS:243-249 for both endpoints of every edge) do not depend on the pixel:
 // rz_project_boxes computes them once per frame with the very same operations, plus a conservative screen-space

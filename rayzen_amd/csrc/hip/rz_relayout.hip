@@ -23,16 +23,9 @@
 
 #include "rayzen_hip.h"
 #include "rz_device_math.h"
-#include "rz_scene_dev.h"
+#include "rz_internal.h"
 
 namespace rz {
-
-struct RelayoutView {           // in: the three offsets; out: everything else
-    int nodeOff, triOff, gTriOff;
-    int pairBase, triBase;      // where this view's pairs / triangles start in the global arrays (in)
-    int nPairs, nSlots, depth, rootEnc, empty;
-    float rootMin[3], rootMax[3];
-};
 
 struct RelayoutErr { int code; int detail; unsigned transparent; int maxSlot; };   // device word block
 enum : int { RL_OK = 0, RL_BAD_CHILD = 1, RL_BAD_LEAF = 2, RL_BAD_TRI = 3, RL_BAD_MAT = 4, RL_NOT_A_TREE = 5 };

@@ -28,7 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include "rayzen_hip.h"
-#include "rz_scene_dev.h"
+#include "rz_internal.h"
 
 namespace rz {
 
