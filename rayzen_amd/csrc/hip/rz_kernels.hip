@@ -797,8 +797,10 @@ SamplesPlan plan_render_samples(int spp, int nSlots, bool glass) {
     // must hold at most RZ_CLAIM_UNITS (pixel, 64-sample batch) units
     bool compact = RZ_COMPACT_DEFAULT != 0;
     if (const char* e = std::getenv("RZ_COMPACT")) compact = std::atoi(e) != 0;                            // A/B aid
-    // (measured: C2, 64 spp, 14.29 -> 13.28 ms; 128 spp C5 144.2 -> 143.0; at 256 spp a claim is 2 pixels and the gain is gone)
-    p.compact = compact && !glass && p.perClaim > 0 && nBatches <= 2 && spp >= 64;      // (a unit is ONE pixel's batch of 64 samples)
+    // (measured: C2, 64 spp, 14.29 -> 13.28 ms; 128 spp C5 144.2 -> 143.0.  Up to RZ_CLAIM_UNITS batches per pixel -- a claim is
+    //  then one or two pixels' batches: at mid-round the gain was gone at 256 spp, on the final code it is back: C3 47.3 -> 44.7 ms,
+    //  one rank's share of a 4- / 8-GPU weak-scaling frame (256 / 512 spp) 11.88 -> 11.25 / 11.85 -> 11.70 ms)
+    p.compact = compact && !glass && p.perClaim > 0 && nBatches <= RZ_CLAIM_UNITS && spp >= 64;      // (a unit is ONE pixel's batch of 64 samples)
     if (p.compact) p.perClaim = std::max(1, std::min(p.perClaim, RZ_CLAIM_UNITS / nBatches));
     const long long claims = p.perClaim ? (p.groups + p.perClaim - 1) / p.perClaim : p.groups;
     p.grid = p.perClaim ? std::min<long long>(claims, (long long)nCU * RZ_PERSIST_WAVES_PER_CU) : p.groups;
