@@ -634,8 +634,8 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     }
     K.claimScratch = nullptr;
     if (plan.compact && K.maxBounces < 65536) {          // per resident wave: the claim's addends + the pool of parked paths (rz_scene_dev.h)
-        size_t stride = RZ_CLAIM_SCRATCH_DWORDS + RZ_CLAIM_STRIDE_PAD;
-        if (const char* e = std::getenv("RZ_CLAIM_STRIDE_PAD")) stride = RZ_CLAIM_SCRATCH_DWORDS + (size_t)std::max(0, std::atoi(e));   // tuning aid (dwords)
+        size_t stride = claim_scratch_dwords(plan.claimUnits) + RZ_CLAIM_STRIDE_PAD;
+        if (const char* e = std::getenv("RZ_CLAIM_STRIDE_PAD")) stride = claim_scratch_dwords(plan.claimUnits) + (size_t)std::max(0, std::atoi(e));   // tuning aid (dwords)
         rc = ensure(c, c->dClaimScratch, (size_t)plan.grid * stride * sizeof(float));
         if (rc != RZ_OK) return rc;
         K.claimScratch = static_cast<float*>(c->dClaimScratch.p);

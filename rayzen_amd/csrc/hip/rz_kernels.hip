@@ -466,7 +466,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
 // ---------------------------------------------------------------------------------------------------------
 // render_claim_compact: the opaque spp >= 64 persistent path with RAY COMPACTION across the pixels of a claim
 // (north_star: "wavefront ballot / prefix-sum ray compaction for divergent bounces").
-// A claim is up to RZ_CLAIM_UNITS (pixel, 64-sample batch) units.  The wave runs the units one after the other as
+// A claim is up to UNITS (pixel, 64-sample batch) units.  The wave runs the units one after the other as
 // before, but a path that is about to trace its THIRD segment (bounce >= 2: 5 % of C2's paths, scattered over lanes
 // whose neighbours have died) is parked instead: its 13 dwords of state + a back reference go to a pool in the wave's
 // scratch, at slot nPool + (number of parked lanes below it) -- a ballot and a popcount of the lower lanes.  When the
@@ -477,18 +477,18 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
 // of 3 lanes eight times.  A path's arithmetic does not depend on where it runs: same bits.
 // Scratch is private to the resident wave and is only ever read by the wave that wrote it (L1/L2 hits); the
 // __syncthreads() of the one-wave workgroup order its stores before its loads.
-template <bool COUNT, bool OVF>
+template <bool COUNT, bool OVF, int UNITS>
 __device__ __forceinline__ void render_claim_compact(const KParams& K, const unsigned base, const unsigned end, unsigned char* lds_raw) {
     const int lane = threadIdx.x & 63;
     const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + lane,
                                OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + lane : nullptr, K.blasStackCap};
     float* const addBase = K.claimScratch + (size_t)blockIdx.x * K.claimStride;
-    unsigned* const pool = reinterpret_cast<unsigned*>(addBase + (size_t)RZ_CLAIM_UNITS * 6 * 64);
-    constexpr int PS = RZ_CLAIM_UNITS * 64;          // pool stride (slots per field)
+    unsigned* const pool = reinterpret_cast<unsigned*>(addBase + (size_t)UNITS * 6 * 64);
+    constexpr int PS = UNITS * 64;                    // pool stride (slots per field)
     const int spp = K.spp;
     const int nBatches = (spp + 63) / 64;
     const int nPix = (int)(end - base);
-    const int nUnits = nPix * nBatches;               // <= RZ_CLAIM_UNITS by the launch plan
+    const int nUnits = nPix * nBatches;               // <= UNITS by the launch plan
     int nPool = 0, unit = 0, poolBase = 0, poolWrite = 0;     // wave-uniform
     int tileCached = -1, tileX = 0, tileY = 0;                // wave-uniform: the tile of the current unit
     Tally c = {};
@@ -672,7 +672,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
     __syncthreads();        // the next claim overwrites the scratch
 }
 
-template <bool COUNT, bool GLASS, bool OVF, bool COMPACT>
+template <bool COUNT, bool GLASS, bool OVF, int COMPACT>      // COMPACT: 0, or the units of a compacting claim (8 / 16)
 __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES_MIN_WAVES) void rz_render_samples(const KParams K, const unsigned nGroups, const unsigned perClaim) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 #ifdef RZ_PROF
@@ -692,8 +692,8 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
         ++wl_claims;
 #endif
         const unsigned end = base + perClaim < nGroups ? base + perClaim : nGroups;
-        if constexpr (COMPACT && !GLASS) {
-            render_claim_compact<COUNT, OVF>(K, base, end, lds_raw);
+        if constexpr (COMPACT != 0 && !GLASS) {
+            render_claim_compact<COUNT, OVF, COMPACT>(K, base, end, lds_raw);
         } else {
             for (unsigned wb = base; wb < end; ++wb) render_samples_group<COUNT, GLASS, OVF>(K, wb, lds_raw);
         }
@@ -782,26 +782,34 @@ SamplesPlan plan_render_samples(int spp, int nSlots, bool glass) {
                   ? prop.multiProcessorCount : 256;
     }
     const int nBatches = (spp + 63) / 64;
-    // A claim is sized in WORK, RZ_GROUPS_PER_CLAIM (pixel, 64-sample batch) units: 8 pixels at 64 spp, 2 at 256, 1 from
-    // 512 on.  (Sized in pixels, one rank's share of an 8-GPU weak-scaling frame -- 1/8 of the tiles at 512 spp -- was
-    // 4 050 claims for 4 096 waves: 21.9 ms for the work of an 11.3-ms frame, 12.2 ms now.)
-    // Small launches (under 3/4 M units: a 1/4 or 1/8 share of a 1080p frame at 64 spp) take half-size claims: a claim in the
-    // middle of the bunny lasts ten times the average and the launch cannot end before the last such claim has run -- with
-    // 8-unit claims a 1/8-frame launch took 2.80 ms for 1.41 ms of work, with 4-unit claims 1.93 (rank_share.py; the
-    // RZ_PROF wave log shows the resident waves draining over the second half of such a launch).  A full frame keeps 8:
-    // its claims compact better (11.3 against 12.3 ms; a half frame 5.87 against 6.15) and its tail is 0.3 ms.
-    const int claimUnits = p.groups * nBatches >= (3ll << 18) ? RZ_GROUPS_PER_CLAIM : std::max(1, RZ_GROUPS_PER_CLAIM / 2);
+    const long long units = p.groups * nBatches;        // (pixel, 64-sample batch) units of work in this launch
+    // A claim is sized in WORK, in units, whatever the spp (sized in pixels -- 8 -- one rank's share of an 8-GPU
+    // weak-scaling frame, 1/8 of the tiles at 512 spp, was 4 050 claims for 4 096 waves: 21.9 ms for the work of an 11.3-ms
+    // frame), and by the size of the launch:
+    //  *  4 units under 3/4 M units (a 1/4 or 1/8 share of a 1080p frame at 64 spp): a claim in the middle of the bunny lasts
+    //     ten times the average and the launch cannot end before the last such claim has run -- with 8-unit claims a 1/8-frame
+    //     launch took 2.80 ms for 1.41 ms of work, with 4-unit claims 1.93 (rank_share.py; the RZ_PROF wave log shows the
+    //     resident waves draining over the second half of such a launch);
+    //  *  8 units for a 1080p frame at 64-128 spp: its claims compact better than 4-unit ones (11.3 against 12.3 ms; a half
+    //     frame 5.87 against 6.15) and its tail is 0.3 ms; 12 and 16 units: 11.04 -> 11.10 / 11.27 ms;
+    //  * 16 units from 4 M units on (C3: 256 spp at 1080p; C5: 128 spp at 4K): more pixels per claim, so more paths to compact
+    //     and more lanes in the ordered sums, and the tail no longer shows: C3 44.7 -> 43.0 ms, C5 118.2 -> 115.6.
+    const int claimUnits = units >= (4ll << 20) ? RZ_CLAIM_UNITS_LARGE : (units >= (3ll << 18) ? RZ_GROUPS_PER_CLAIM : std::max(1, RZ_GROUPS_PER_CLAIM / 2));
     p.perClaim = (spp >= 64 && p.groups >= (long long)nCU * RZ_PERSIST_WAVES_PER_CU * 16) ? std::max(1, claimUnits / nBatches) : 0;
     if (const char* e = std::getenv("RZ_GROUPS_PER_CLAIM")) p.perClaim = std::max(0, std::atoi(e));      // tuning aid
-    // ray compaction across the units of a claim (render_claim_compact): opaque scenes, persistent launches, and a claim
-    // must hold at most RZ_CLAIM_UNITS (pixel, 64-sample batch) units
+    // ray compaction across the units of a claim (render_claim_compact, instantiated for 8 and for 16 units): opaque scenes,
+    // persistent launches, up to 16 batches per pixel (a unit is ONE pixel's batch of 64 samples)
     bool compact = RZ_COMPACT_DEFAULT != 0;
     if (const char* e = std::getenv("RZ_COMPACT")) compact = std::atoi(e) != 0;                            // A/B aid
-    // (measured: C2, 64 spp, 14.29 -> 13.28 ms; 128 spp C5 144.2 -> 143.0.  Up to RZ_CLAIM_UNITS batches per pixel -- a claim is
-    //  then one or two pixels' batches: at mid-round the gain was gone at 256 spp, on the final code it is back: C3 47.3 -> 44.7 ms,
-    //  one rank's share of a 4- / 8-GPU weak-scaling frame (256 / 512 spp) 11.88 -> 11.25 / 11.85 -> 11.70 ms)
-    p.compact = compact && !glass && p.perClaim > 0 && nBatches <= RZ_CLAIM_UNITS && spp >= 64;      // (a unit is ONE pixel's batch of 64 samples)
-    if (p.compact) p.perClaim = std::max(1, std::min(p.perClaim, RZ_CLAIM_UNITS / nBatches));
+    // (measured: C2, 64 spp, 14.29 -> 13.28 ms; 128 spp C5 144.2 -> 143.0.  Several batches per pixel -- a claim is then a few
+    //  pixels' batches: at mid-round the gain was gone at 256 spp, on the final code it is back: C3 47.3 -> 44.7 ms, one rank's
+    //  share of a 4- / 8-GPU weak-scaling frame (256 / 512 spp) 11.88 -> 11.25 / 11.85 -> 11.70 ms)
+    p.compact = compact && !glass && p.perClaim > 0 && nBatches <= RZ_CLAIM_UNITS_LARGE && spp >= 64;
+    p.claimUnits = 0;
+    if (p.compact) {
+        p.claimUnits = (p.perClaim * nBatches > RZ_CLAIM_UNITS_SMALL) ? RZ_CLAIM_UNITS_LARGE : RZ_CLAIM_UNITS_SMALL;
+        p.perClaim = std::max(1, std::min(p.perClaim, p.claimUnits / nBatches));
+    }
     const long long claims = p.perClaim ? (p.groups + p.perClaim - 1) / p.perClaim : p.groups;
     p.grid = p.perClaim ? std::min<long long>(claims, (long long)nCU * RZ_PERSIST_WAVES_PER_CU) : p.groups;
     return p;
@@ -823,14 +831,17 @@ void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream
     const bool ovf = K.blasOvfCap > 0;           // only set for persistent launches (rz_context.hip: render_samples)
 #define RZ_LAUNCH_SAMPLES(C, G, O, M) hipLaunchKernelGGL((rz_render_samples<C, G, O, M>), g, b, lds, stream, K, nGroups, (unsigned)perClaim)
     if (glass) {
-        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, true, true, false); else RZ_LAUNCH_SAMPLES(true, true, false, false); }
-        else { if (ovf) RZ_LAUNCH_SAMPLES(false, true, true, false); else RZ_LAUNCH_SAMPLES(false, true, false, false); }
+        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, true, true, 0); else RZ_LAUNCH_SAMPLES(true, true, false, 0); }
+        else { if (ovf) RZ_LAUNCH_SAMPLES(false, true, true, 0); else RZ_LAUNCH_SAMPLES(false, true, false, 0); }
+    } else if (compact && plan.claimUnits == RZ_CLAIM_UNITS_LARGE) {
+        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, false, true, RZ_CLAIM_UNITS_LARGE); else RZ_LAUNCH_SAMPLES(true, false, false, RZ_CLAIM_UNITS_LARGE); }
+        else { if (ovf) RZ_LAUNCH_SAMPLES(false, false, true, RZ_CLAIM_UNITS_LARGE); else RZ_LAUNCH_SAMPLES(false, false, false, RZ_CLAIM_UNITS_LARGE); }
     } else if (compact) {
-        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, false, true, true); else RZ_LAUNCH_SAMPLES(true, false, false, true); }
-        else { if (ovf) RZ_LAUNCH_SAMPLES(false, false, true, true); else RZ_LAUNCH_SAMPLES(false, false, false, true); }
+        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, false, true, RZ_CLAIM_UNITS_SMALL); else RZ_LAUNCH_SAMPLES(true, false, false, RZ_CLAIM_UNITS_SMALL); }
+        else { if (ovf) RZ_LAUNCH_SAMPLES(false, false, true, RZ_CLAIM_UNITS_SMALL); else RZ_LAUNCH_SAMPLES(false, false, false, RZ_CLAIM_UNITS_SMALL); }
     } else {
-        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, false, true, false); else RZ_LAUNCH_SAMPLES(true, false, false, false); }
-        else { if (ovf) RZ_LAUNCH_SAMPLES(false, false, true, false); else RZ_LAUNCH_SAMPLES(false, false, false, false); }
+        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, false, true, 0); else RZ_LAUNCH_SAMPLES(true, false, false, 0); }
+        else { if (ovf) RZ_LAUNCH_SAMPLES(false, false, true, 0); else RZ_LAUNCH_SAMPLES(false, false, false, 0); }
     }
 #undef RZ_LAUNCH_SAMPLES
 }

@@ -121,7 +121,7 @@ struct KParams {
     int32_t blasOvfCap;     // entries per lane beyond the LDS window, kept in global memory (persistent launches only; else 0)
     uint2* blasOvf;         // [resident wave][blasOvfCap][64 lanes]
     float* claimScratch;    // compacting launches (rz_kernels.hip: render_claim_compact): per resident wave, addends + survivor pool
-    uint32_t claimStride;   // dwords from one resident wave's scratch to the next (>= RZ_CLAIM_SCRATCH_DWORDS)
+    uint32_t claimStride;   // dwords from one resident wave's scratch to the next (>= claim_scratch_dwords(units of the launch))
     const DevTriN* triN;    // [triangle in leaf order] (rz_trace.h: trace_closest's epilogue)
     float hemi0[3];         // rz_path.h: hemisphere_local((+0, +0)), the local direction of every bounce-0 scatter (rz_hemi0_kernel, once per context)
 };
@@ -145,15 +145,13 @@ struct TlasWork {
 
 // How rz_render_samples is launched (rz_kernels.hip: plan_render_samples): groups of pixels, the grid, and the number
 // of groups a persistent wave claims per atomic (0: one workgroup per group).
-struct SamplesPlan { long long groups, grid; int perClaim; bool compact; };
+struct SamplesPlan { long long groups, grid; int perClaim; bool compact; int claimUnits; };   // claimUnits: 8 or 16 when compact
 
-// Per resident wave of a compacting launch: the two addends of every sample of up to RZ_CLAIM_UNITS (pixel, batch) units
-// [unit][6][64] floats, then the pool of parked paths [RZ_POOL_FIELDS][RZ_CLAIM_UNITS * 64] dwords.
-#ifndef RZ_CLAIM_UNITS_N
-#define RZ_CLAIM_UNITS_N 8
-#endif
-constexpr int RZ_CLAIM_UNITS = RZ_CLAIM_UNITS_N;
+// Per resident wave of a compacting launch: the two addends of every sample of up to `units` (pixel, batch) units
+// [unit][6][64] floats, then the pool of parked paths [RZ_POOL_FIELDS][units * 64] dwords.  The kernel is instantiated for
+// claims of 8 and of 16 units (rz_kernels.hip: plan_render_samples picks by the size of the launch).
+constexpr int RZ_CLAIM_UNITS_SMALL = 8, RZ_CLAIM_UNITS_LARGE = 16;
 constexpr int RZ_POOL_FIELDS = 14;
-constexpr size_t RZ_CLAIM_SCRATCH_DWORDS = (size_t)RZ_CLAIM_UNITS * 6 * 64 + (size_t)RZ_POOL_FIELDS * RZ_CLAIM_UNITS * 64;
+constexpr size_t claim_scratch_dwords(int units) { return (size_t)units * 6 * 64 + (size_t)RZ_POOL_FIELDS * units * 64; }
 
 }  // namespace rz

@@ -161,11 +161,11 @@ def _band_check(sc, W, H, spp, b, got, y0=None, rows=8):
     assert (g.view(np.uint32) == o.view(np.uint32)).all(), mismatch_report(g, o)
 
 
-@pytest.mark.parametrize("W,H,spp", [(1280, 1024, 64), (1283, 1021, 100), (1280, 1024, 128), (640, 512, 192), (643, 509, 300), (640, 512, 512), (640, 512, 520)])
+@pytest.mark.parametrize("W,H,spp", [(1280, 1024, 64), (1283, 1021, 100), (1280, 1024, 128), (640, 512, 192), (643, 509, 300), (640, 512, 512), (640, 512, 520), (648, 512, 1024), (640, 512, 1100)])
 def test_compacting_launch_equals_the_plain_one_and_the_oracle(W, H, spp, monkeypatch):
     """Frame sizes that are / are not multiples of the 8x8 tile; one, two, three, five and eight 64-sample batches per pixel
-    (the last one partly filled; a claim is then 8, 4, 2, 1, 1 pixels), nine batches (more than a claim's units: the
-    plain persistent launch); 5 bounces so that paths are parked and re-parked: compaction on == compaction off ==
+    (the last one partly filled; a claim is then 4, 2, 1 ... pixels of the 8- or the 16-unit instantiation), nine and sixteen
+    batches (16-unit claims of one pixel), eighteen (more than a claim's units: the plain persistent launch); 5 bounces so that paths are parked and re-parked: compaction on == compaction off ==
     oracle band."""
     sc = S.bunny_scene(n=16, aspect=W / H)
     b = 5
