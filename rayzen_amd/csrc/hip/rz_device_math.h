@@ -91,7 +91,8 @@ __device__ __forceinline__ bool rcp_mid_ok(float x) {       // false for NaN, ze
 }
 // (1/x, 1/y, 1/z) of a ray direction
 __device__ __forceinline__ v3 rcp3(v3 d) {
-    const bool ok = rcp_mid_ok(d.x) & rcp_mid_ok(d.y) & rcp_mid_ok(d.z);
+    const bool okx = rcp_mid_ok(d.x), oky = rcp_mid_ok(d.y), okz = rcp_mid_ok(d.z);
+    const bool ok = okx & oky & okz;
     if (rz_ballot(!ok) == 0ull) return mk3(rcp_mid(d.x), rcp_mid(d.y), rcp_mid(d.z));
     return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 }
