@@ -35,6 +35,32 @@ MAX_CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md "Max clock"
 ISSUE_CYCLES_PER_INST = 2.0     # a SIMD issues at most one wave64 instruction per 2 cycles (profiles/r02_valu_issue)
 ISSUE_PEAK_GINST = SIMDS * MAX_CLOCK_HZ / ISSUE_CYCLES_PER_INST / 1e9
 PMC_JSON = os.path.join(ROOT, "profiles", "r02b_c2_kernel", "pmc_rz_render_samples.json")
+# Measured issue cost (SIMD cycles per wave64 instruction with four waves resident, profiles/r02_valu_issue/valu_issue.txt)
+# of the VALU classes the SQ counters tell apart; "other" = comparisons, selects, min / max, moves, lane reads.  The f32
+# add / mul / fma class mixes 2-cycle scalar-free forms with 3.5-cycle packed and SGPR-operand forms (2.6 assumed), int32
+# mixes 1.9-cycle adds / ands with 3.4-cycle shifts (2.7 assumed); non-vector instructions are priced at the 2.0 cycles
+# they cost when interleaved with vector ones.  A MODEL of how busy this instruction mix keeps the SIMDs, not a counter.
+MIX_COST = {"SQ_INSTS_VALU_TRANS_F32": 6.57, "SQ_INSTS_VALU_TRANS_F64": 12.7, "SQ_INSTS_VALU_ADD_F64": 3.52,
+            "SQ_INSTS_VALU_MUL_F64": 3.52, "SQ_INSTS_VALU_FMA_F64": 3.52, "SQ_INSTS_VALU_CVT": 3.5, "SQ_INSTS_VALU_INT64": 3.45,
+            "SQ_INSTS_VALU_INT32": 2.7, "SQ_INSTS_VALU_ADD_F32": 2.6, "SQ_INSTS_VALU_MUL_F32": 2.6, "SQ_INSTS_VALU_FMA_F32": 2.6}
+MIX_COST_OTHER_VALU, MIX_COST_NON_VALU = 3.4, 2.0
+
+
+def mix_model(pj, kernel_s, clock_hz):
+    """Issue cycles this launch's instruction mix needs at the measured per-class costs / SIMD cycles it had."""
+    if not all(k in pj for k in MIX_COST):
+        return None
+    classed = sum(pj[k] for k in MIX_COST)
+    valu_cycles = sum(pj[k] * c for k, c in MIX_COST.items()) + max(0.0, pj["SQ_INSTS_VALU"] - classed) * MIX_COST_OTHER_VALU
+    other = sum(pj[k] for k in INST_COUNTERS if k != "SQ_INSTS_VALU")
+    have = kernel_s * clock_hz * SIMDS
+    return {"valu_cycles": int(valu_cycles), "non_valu_cycles": int(other * MIX_COST_NON_VALU), "simd_cycles_available": int(have),
+            "busy_frac_valu_only": round(valu_cycles / have, 3), "busy_frac": round((valu_cycles + other * MIX_COST_NON_VALU) / have, 3),
+            "clock_ghz_assumed": round(clock_hz / 1e9, 2),
+            "note": "mix-weighted issue model (per-class costs from profiles/r02_valu_issue): the instruction mix of this launch keeps "
+                    "the SIMDs busy for this fraction of the kernel's duration; a model, not a counter"}
+
+
 INST_COUNTERS = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
                  "SQ_INSTS_VMEM_WR", "SQ_INSTS_BRANCH")
 
@@ -266,6 +292,15 @@ def main():
                                  "instruction_mix": {k[9:].lower(): int(pj[k]) for k in INST_COUNTERS},
                                  "valu_lane_utilisation": round(pj["SQ_THREAD_CYCLES_VALU"] / (64.0 * pj["SQ_ACTIVE_INST_VALU"]), 3),
                                  "counters_from": os.path.relpath(PMC_JSON, ROOT), "counters_source_hash": src_hash[:16]})
+                    # in-kernel clock under this load: GRBM_GUI_ACTIVE (sum over 8 XCDs) / 8 / the profiled duration
+                    clk = 2.39e9
+                    try:
+                        clk = pj["GRBM_GUI_ACTIVE"] / 8.0 / (pj["_dispatch"]["duration_ns_under_profiler"] * 1e-9)
+                    except Exception:
+                        pass
+                    mm = mix_model(pj, kernel_s, clk)
+                    if mm:
+                        roof["mix_model"] = mm
                     hbm.update({"counter_traffic_GBps": round(traffic / kernel_s / 1e9, 1),
                                 "counter_traffic_over_peak": round(traffic / kernel_s / 1e9 / HBM_PEAK_GBPS, 4)})
                 else:
