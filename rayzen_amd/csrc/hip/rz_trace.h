@@ -113,12 +113,16 @@ struct HitRec {
 
 // Number of lanes for which p holds, compared on the scalar unit (written with __popcll the compiler widened the count
 // to 64 bits and compared it with a VECTOR instruction, v_cmp_gt_u64 on an SGPR pair, plus two mask operations).
-__device__ __forceinline__ int wave_count(bool p) {
+__device__ __forceinline__ int mask_count(unsigned long long m) {
     int n;
-    const unsigned long long m = rz_ballot(p);
     asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
     return n;
 }
+__device__ __forceinline__ int wave_count(bool p) { return mask_count(rz_ballot(p)); }
+// The lanes of a mask, as a predicate: `if (in_mask(m))` is s_and_saveexec with m itself -- the loops below compute the
+// mask of the NEXT trip at the end of a trip (their exit test needs it) and enter the body by it, instead of evaluating
+// the same comparison a second time at the head (a v_cmp is a 4-cycle instruction here).
+__device__ __forceinline__ bool in_mask(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 // FS:380-388.  Returns the hit flag; tmin as the shader computes it.
 __device__ __forceinline__ bool slab(v3 o, v3 inv, float bx0, float by0, float bz0, float bx1, float by1, float bz1,
@@ -310,10 +314,10 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
 #endif
         // (the lane-count test sits at the END of the body: lanes at internal nodes always advance at least one step per
         //  round of the outer loop, or one to three stragglers with nobody at a leaf would never move again)
-        bool more = rz_ballot(cur >= 0) != 0ull;
+        unsigned long long actMask = rz_ballot(cur >= 0);
+        bool more = actMask != 0ull;
         while (more) {
-            const bool act = cur >= 0;
-            if (act) {
+            if (in_mask(actMask)) {
                 RZ_SITE(c, 3);
                 const DevPair* pp = pairs + cur;
                 if (COUNT) c.blas_nodes += 2;        // the shader pushes, and later pops, both children
@@ -362,7 +366,8 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
                     step(hl, tl, hr, tr, __float_as_int(p3.x), __float_as_int(p3.y));
                 }
             }
-            more = wave_count(cur >= 0) >= RZ_DESCEND_MIN_LANES;
+            actMask = rz_ballot(cur >= 0);
+            more = mask_count(actMask) >= RZ_DESCEND_MIN_LANES;
         }
 #ifdef RZ_PROF
         const unsigned long long td1_ = __builtin_amdgcn_s_memtime();
@@ -378,9 +383,10 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
             if (COUNT) c.triangles += (unsigned)count;
             if (leaf) RZ_SITE(c, 1);
             int i = 0;
-            bool any = rz_ballot(0 < count) != 0ull;
+            unsigned long long triMask = rz_ballot(0 < count);
+            bool any = triMask != 0ull;
             while (any) {
-                if (i < count) {
+                if (in_mask(triMask)) {
                     RZ_SITE(c, 2);
                     const float4* __restrict__ tp = reinterpret_cast<const float4*>(tris + first + i);
                     float4 a = tp[0], b = tp[1], cc = tp[2];
@@ -390,7 +396,8 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
                     if (hit && t < tLoc) { tLoc = t; best = first + i; }
                 }
                 ++i;
-                any = rz_ballot(i < count) != 0ull;
+                triMask = rz_ballot(i < count);
+                any = triMask != 0ull;
             }
             if (leaf) {
                 if (!pop_entry(bstk, sp, tLoc, cur)) cur = -1;
