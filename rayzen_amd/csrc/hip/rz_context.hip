@@ -737,6 +737,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
         for (int k = 0; k < 8; ++k)
             fprintf(stderr, "[rz_prof] %-16s wave-execs %12llu  lanes %14llu  avg active lanes %.1f\n", names[k], pr[2 * k], pr[2 * k + 1], pr[2 * k] ? (double)pr[2 * k + 1] / (double)pr[2 * k] : 0.0);
         fprintf(stderr, "[rz_prof] wave cycles: begin %llu  trace %llu  advance %llu | inside trace: descend loops %llu  leaf phases %llu  whole BLAS walks %llu\n", pr[16], pr[17], pr[18], pr[19], pr[20], pr[21]);
+        fprintf(stderr, "[rz_prof] compacting claims: phase 1 (units) %llu  pool rounds %llu wave cycles; %llu rounds with %llu paths = %.1f lanes per round\n", pr[23], pr[28], pr[29], pr[30], pr[29] ? (double)pr[30] / (double)pr[29] : 0.0);
         fprintf(stderr, "[rz_prof] inside advance: sky %llu  hit %llu  start_light %llu  shade_light %llu  scatter %llu (hemisphere %llu)  shadow step %llu\n", pr[22], pr[23], pr[24], pr[25], pr[26], pr[27], pr[28]);
 #endif
     }

@@ -172,7 +172,7 @@ __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
     a.light_fetches += b.light_fetches; a.samples += b.samples;
 #ifdef RZ_PROF
     for (int k = 0; k < 16; ++k) a.p[k] += b.p[k];
-    for (int k = 0; k < 10; ++k) a.t[k] += b.t[k];
+    for (int k = 0; k < 12; ++k) a.t[k] += b.t[k];
 #endif
 }
 
@@ -498,6 +498,9 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
     bool cont;
     do {                                                        // (one exit, at the end: see blas_walk; the bound is a backstop: units + pool rounds of at most maxBounces generations)
         const bool phase2 = unit >= nUnits;
+#ifdef RZ_PROF
+        const unsigned long long tph0_ = __builtin_amdgcn_s_memtime();
+#endif
         int backUnit = 0, backLane = lane;
         bool poolLane = false;
         P.mode = MODE_DONE;
@@ -595,6 +598,13 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
             poolWrite += __popcll(pm);
             poolBase += 64;
         }
+#ifdef RZ_PROF
+        {   // diagnostic build: wave cycles and lane occupancy of the two phases of a claim
+            const unsigned long long dt_ = __builtin_amdgcn_s_memtime() - tph0_;
+            if (phase2) { c.t[9] += dt_; c.t[10] += 1; c.t[11] += (unsigned long long)__popcll(rz_ballot(poolLane)); }   // pool rounds and the paths in them
+            else { c.t[4] += dt_; }
+        }
+#endif
         cont = true;
         if (unit >= nUnits && poolBase >= nPool) {      // this generation is through: the paths it left behind form the next one
             if (poolWrite == 0) {
@@ -668,6 +678,11 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
             for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
             if (lane == 0 && x) atomicAdd(&g[k], (unsigned long long)x);
         }
+#ifdef RZ_PROF
+        unsigned long long* pr = reinterpret_cast<unsigned long long*>(K.counters + 1);
+        for (int k = 0; k < 16; ++k) if (c.p[k]) atomicAdd(&pr[k], (unsigned long long)c.p[k]);
+        if (lane == 0) for (int k = 0; k < 12; ++k) atomicAdd(&pr[19 + k], c.t[k]);
+#endif
     }
     __syncthreads();        // the next claim overwrites the scratch
 }

@@ -42,7 +42,7 @@ struct Tally {          // per-thread counts of the REFERENCE algorithm's memory
         samples;
 #ifdef RZ_PROF          // diagnostic build only: where do the lanes of a wave spend their iterations?
     unsigned p[16];
-    unsigned long long t[10];   // wave cycles (s_memtime): [0] descend loops, [1] leaf phases, [2] whole BLAS walks; rz_path.h advance(): [3] sky, [4] hit bookkeeping, [5] start_light, [6] shade_light, [7] scatter, [8] of it the hemisphere direction, [9] shadow-step bookkeeping
+    unsigned long long t[12];   // ([4] / [9]: phase 1 / pool rounds of a compacting claim, [10] pool rounds, [11] paths in them)   wave cycles (s_memtime): [0] descend loops, [1] leaf phases, [2] whole BLAS walks; rz_path.h advance(): [3] sky, [4] hit bookkeeping, [5] start_light, [6] shade_light, [7] scatter, [8] of it the hemisphere direction, [9] shadow-step bookkeeping
 #endif
 };
 #ifdef RZ_PROF
