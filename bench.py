@@ -278,7 +278,12 @@ def main():
                              "(measured issue limit of a gfx950 SIMD, vector and scalar instructions alike: profiles/r02_valu_issue)"}
         # instruction counts and HBM traffic come from rocprofv3 --pmc passes (they cannot be read in-process); they are
         # deterministic per (build, workload), so they are only used when they were captured from THIS build and workload
-        src_hash = rzbuild.source_hash()
+        # ... which is decided on the hash compiled into the LOADED library (rz_source_hash), not on the files beside it
+        from rayzen_amd import _lib as rzlib
+        src_hash = rzlib.hip().rz_source_hash().decode()
+        tree_hash = rzbuild.source_hash()
+        out["library"] = {"path": os.path.relpath(rzlib.HIP_SO, ROOT), "source_hash": src_hash[:16], "tree_source_hash": tree_hash[:16],
+                          "built_from_this_tree": src_hash == tree_hash}
         if world == 1 and os.path.exists(PMC_JSON):
             try:
                 pj = json.load(open(PMC_JSON))

@@ -342,11 +342,31 @@ void* rz_group_frame_device_ptr(rz_group* g);
  * rayzen_amd/csrc/hip/rz_scene_dev.h).  out NULL: only *needed is set.  Runs the pending re-layout first. */
 int rz_debug_read_layout(rz_ctx* ctx, int which, void* out, size_t bytes, size_t* needed);
 
+/* TEST HOOK: how the last rz_render / rz_render_counted of this context was launched (rz_kernels.hip:
+ * plan_render_samples).  A (pixel, 64-sample batch) pair is one "unit" of work; persistent launches hand their waves
+ * `per_claim` pixel groups per atomic, compacting ones work off `claim_units`-unit claims. */
+typedef struct rz_launch_plan {
+    int64_t groups;             /* pixel groups of the launch (one wave's pixels: 1 pixel when spp >= 64, else 64 / spp) */
+    int64_t grid;               /* workgroups launched (one wave each) */
+    int32_t per_claim;          /* groups a persistent wave claims per atomic; 0 = one workgroup per group */
+    int32_t claim_units;        /* units of a compacting claim (8 or 16); 0 = the launch does not compact */
+    int32_t batches_per_pixel;  /* ceil(spp / 64) */
+    int32_t pixels_per_wave;    /* 1, or 64 / spp when spp < 64 */
+    int32_t lds_stack_entries;  /* BLAS stack entries per lane kept in LDS */
+    int32_t overflow_entries;   /* ... and in the global overflow columns (0: the whole stack fits the LDS window) */
+    int32_t transparent;        /* 1: the scene has a transparent material (the speculating variant of the kernel) */
+    int32_t reserved;
+} rz_launch_plan;
+int rz_debug_last_plan(rz_ctx* ctx, rz_launch_plan* out);
+
 /* Number of HIP devices visible to the process (0 without a GPU). */
 int rz_device_count(void);
 
 /* Library/version probe that needs no GPU. */
 const char* rz_version(void);
+/* sha256 (64 hex digits) of the sources and compiler flags this library was built from (rayzen_amd/build.py:
+ * source_hash), or "unstamped": ties the LOADED library to a source tree and to a committed profile.  Needs no GPU. */
+const char* rz_source_hash(void);
 /* sizeof() of the ABI structs as compiled into the library, for layout
  * checks from other languages: which = 0 triangle, 1 node, 2 instance,
  * 3 material, 4 light, 5 frame_params, 6 counters. */

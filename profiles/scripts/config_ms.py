@@ -8,6 +8,8 @@ from rayzen_amd.renderer import Renderer, frame_params
 
 cfgs = {"c2": lambda: (S.bunny_scene(n=76, aspect=16 / 9), 1920, 1080, 64, 4),
         "c2g": lambda: (S.bunny_scene(n=76, aspect=16 / 9, extras=True), 1920, 1080, 64, 4),
+        "glassbunny": lambda: (S.bunny_scene(n=76, aspect=16 / 9, bunny_material=3), 1920, 1080, 64, 4),
+        "ref": lambda: (S.reference_scene(aspect=800 / 600), 800, 600, 1, 5),
         "c4": lambda: (S.instanced_scene(n=76, count=16, aspect=16 / 9), 1920, 1080, 16, 4),
         "c5": lambda: (S.stress_scene(n=289, aspect=16 / 9), 3840, 2160, 32, 8),
         "c5full": lambda: (S.stress_scene(n=289, aspect=16 / 9), 3840, 2160, 128, 8),

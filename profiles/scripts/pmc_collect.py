@@ -74,8 +74,9 @@ def main():
     summary["_workload"] = workload
     try:                                 # which build the counters belong to (rayzen_amd/build.py: source_hash)
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-        from rayzen_amd import build as rzbuild
-        summary["_source_hash"] = rzbuild.source_hash()
+        from rayzen_amd import _lib as rzlib        # the hash compiled into the library the profiled command loads (RAYZEN_HIP_SO is honoured)
+        summary["_source_hash"] = rzlib.hip().rz_source_hash().decode()
+        summary["_library"] = os.path.relpath(rzlib.HIP_SO)
     except Exception as e:
         summary["_source_hash"] = f"unavailable: {e}"
     json.dump(summary, open(out_json, "w"), indent=1)

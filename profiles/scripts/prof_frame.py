@@ -14,6 +14,11 @@ if which == "c2":
     sc = S.bunny_scene(n=76, aspect=W / H)
 elif which == "c4":
     sc, SPP = S.instanced_scene(n=76, count=16, aspect=W / H), 16
+elif which == "c2g":
+    sc = S.bunny_scene(n=76, aspect=W / H, extras=True)
+elif which == "ref":        # RayZen's own workload: 800x600, 1 spp, 5 bounces (main.cpp:35-36, 600; FS:675)
+    W, H, SPP, B = 800, 600, 1, 5
+    sc = S.reference_scene(aspect=W / H)
 elif which == "c5":
     W, H, SPP, B = 3840, 2160, 16, 8
     sc = S.stress_scene(n=289, aspect=W / H)

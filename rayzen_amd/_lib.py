@@ -16,7 +16,7 @@ HIP_SYMBOLS = (
     "rz_set_frame", "rz_set_stream",
     "rz_bind_accum", "rz_render", "rz_render_counted", "rz_sync", "rz_clear_accum", "rz_read_accum",
     "rz_resolve_rgba8", "rz_present", "rz_last_render_ms", "rz_render_history_ms", "rz_last_kernel_name", "rz_accum_device_ptr", "rz_version", "rz_sizeof",
-    "rz_debug_fail_alloc", "rz_debug_read_layout", "rz_stream_handle", "rz_device_count",
+    "rz_debug_fail_alloc", "rz_debug_read_layout", "rz_debug_last_plan", "rz_source_hash", "rz_stream_handle", "rz_device_count",
     "rz_group_rccl_version", "rz_group_unique_id", "rz_group_create", "rz_group_create_rank", "rz_group_destroy",
     "rz_group_last_error", "rz_group_size", "rz_group_local_count", "rz_group_rank", "rz_group_ctx", "rz_group_upload",
     "rz_group_update", "rz_group_set_frame", "rz_group_render", "rz_group_reduce", "rz_group_sync", "rz_group_read_frame",
@@ -65,6 +65,13 @@ class MeshBuild(C.Structure):
                 ("index_offset", C.c_int32), ("n_nodes", C.c_int32), ("depth", C.c_int32), ("root", BvhNode)]
 
 
+class LaunchPlan(C.Structure):
+    """rz_launch_plan of include/rayzen_hip.h."""
+    _fields_ = [("groups", C.c_int64), ("grid", C.c_int64), ("per_claim", C.c_int32), ("claim_units", C.c_int32),
+                ("batches_per_pixel", C.c_int32), ("pixels_per_wave", C.c_int32), ("lds_stack_entries", C.c_int32),
+                ("overflow_entries", C.c_int32), ("transparent", C.c_int32), ("reserved", C.c_int32)]
+
+
 class Counters(C.Structure):
     """rz_counters of include/rayzen_hip.h."""
     _fields_ = [(n, C.c_uint64) for n in COUNTER_FIELDS]
@@ -110,6 +117,8 @@ def hip():
         L.rz_sizeof.restype, L.rz_sizeof.argtypes = sz, [i]
         L.rz_debug_fail_alloc.restype, L.rz_debug_fail_alloc.argtypes = i, [vp, i]
         L.rz_debug_read_layout.restype, L.rz_debug_read_layout.argtypes = i, [vp, i, vp, sz, C.POINTER(sz)]
+        L.rz_debug_last_plan.restype, L.rz_debug_last_plan.argtypes = i, [vp, C.POINTER(LaunchPlan)]
+        L.rz_source_hash.restype, L.rz_source_hash.argtypes = C.c_char_p, []
         L.rz_stream_handle.restype, L.rz_stream_handle.argtypes = vp, [vp]
         L.rz_device_count.restype, L.rz_device_count.argtypes = i, []
         L.rz_group_rccl_version.restype, L.rz_group_rccl_version.argtypes = i, [C.POINTER(i)]

@@ -49,13 +49,34 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+STAMP_MARK = b"RZSRCHASH:"      # rz_context.hip keeps "RZSRCHASH:<64 hex digits>" in the library's read-only data
+
+
+def stamped_hash(so_path):
+    """The source hash a librayzen_hip*.so was built from, read from the file (the library is not loaded); None if the
+    file is missing or carries no stamp."""
+    try:
+        blob = open(so_path, "rb").read()
+    except OSError:
+        return None
+    k = blob.find(STAMP_MARK)
+    if k < 0:
+        return None
+    h = blob[k + len(STAMP_MARK):k + len(STAMP_MARK) + 64]
+    return h.decode() if len(h) == 64 and all(c in b"0123456789abcdef" for c in h) else None
+
+
 def build_hip(force=False, verbose=False, extra_flags=()):
+    """Builds librayzen_hip.so unless the one in the tree was built from exactly these sources and flags: the decision is
+    taken on the source hash compiled into the library (rz_source_hash()), not on file times -- a stale library beside
+    fresh sources is rebuilt whatever its mtime says."""
     os.makedirs(LIB, exist_ok=True)
     srcs = _files(HIP_DIR, (".hip",))
-    deps = srcs + _files(HIP_DIR, (".h",)) + _files(INC, (".h",)) + [os.path.abspath(__file__)]
-    if not force and not _newer(HIP_SO, deps):
+    want = source_hash(extra_flags)
+    if not force and stamped_hash(HIP_SO) == want:
         return HIP_SO
-    cmd = [hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + ["-I", INC, "-I", HIP_DIR, "-shared", "-o", HIP_SO] + srcs + ["-ldl"]
+    cmd = ([hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + [f'-DRZ_SOURCE_HASH="{want}"', "-I", INC, "-I", HIP_DIR, "-shared", "-o", HIP_SO]
+           + srcs + ["-ldl"])
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
@@ -75,15 +96,16 @@ def build_host(force=False, verbose=False):
     return HOST_SO
 
 
-def source_hash():
-    """sha256 over everything librayzen_hip.so is built from (sources, headers, flags): ties a committed rocprofv3
-    counter file (profiles/) to the build it was captured from."""
+def source_hash(extra_flags=()):
+    """sha256 over everything librayzen_hip.so is built from (sources, headers, flags).  It is compiled into the library
+    (-DRZ_SOURCE_HASH; rz_source_hash() returns it), so a committed rocprofv3 counter file (profiles/), the tree and the
+    LOADED library can be tied to one another."""
     import hashlib
     h = hashlib.sha256()
     for f in _files(HIP_DIR, (".hip", ".h")) + _files(INC, (".h",)):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
-    h.update(" ".join(HIPCC_FLAGS).encode())
+    h.update(" ".join(HIPCC_FLAGS + list(extra_flags)).encode())
     return h.hexdigest()
 
 

@@ -82,6 +82,7 @@ struct rz_ctx {
     float hemi0[3] = {0.0f, 0.0f, 0.0f};   // KParams::hemi0, computed at rz_create
     long long triNValid = -1;       // triangles dTriN holds normals for (-1: none; reset with the geometry)
     long long lastGrid = 0;         // workgroups of the last render launch (RZ_PROF: how many wave-log entries are valid)
+    rz_launch_plan lastPlan{};      // rz_debug_last_plan
     std::string err;
 
     // host copies of the caller's arrays (the re-layout needs them; rz_update patches them)
@@ -646,6 +647,9 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     RZ_HIP(c, hipEventRecord(c->evStop[evSlot], c->stream));
     c->lastLaunches = K.nSlots > 0 ? 1 : 0;
     c->lastGrid = plan.grid;
+    c->lastPlan = rz_launch_plan{plan.groups, plan.grid, plan.perClaim, (plan.compact && K.claimScratch) ? plan.claimUnits : 0,
+                                 (K.spp + 63) / 64, K.spp >= 64 ? 1 : 64 / K.spp, K.blasStackCap, K.blasOvfCap,
+                                 c->sceneHasTransparency ? 1 : 0, 0};
     return RZ_OK;
 }
 
@@ -697,9 +701,9 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     if (perWave * 4 > 160 * 1024)   // sized for the largest (4-wave) workgroup
         return fail(c, RZ_ERR_BAD_SCENE, "BLAS depth %d needs %zu B of LDS stack per wave; the limit is %d", c->maxBlasDepth, perWave, 40 * 1024);
     if (counted) {
-        rc = ensure(c, c->dCounters, sizeof(DevCounters) + 32 * sizeof(unsigned long long));
+        rc = ensure(c, c->dCounters, sizeof(DevCounters) + 128 * sizeof(unsigned long long));
         if (rc != RZ_OK) return rc;
-        RZ_HIP(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(DevCounters) + 32 * sizeof(unsigned long long), c->stream));
+        RZ_HIP(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(DevCounters) + 128 * sizeof(unsigned long long), c->stream));
         K.counters = static_cast<DevCounters*>(c->dCounters.p);
     }
     // The event pair brackets the render kernels of this call (for the one-lane-per-sample path: the
@@ -715,6 +719,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
         RZ_HIP(c, hipEventRecord(c->evStop[slot], c->stream));
         c->lastLaunches = 1;
         c->lastKernel = "rz_render_pixels";
+        c->lastPlan = rz_launch_plan{K.nLocalTiles, K.nLocalTiles, 0, 0, (K.spp + 63) / 64, 64, K.blasStackCap, 0, c->sceneHasTransparency ? 1 : 0, 0};
     }
     RZ_HIP(c, hipGetLastError());
     c->ringHead = (slot + 1) % rz_ctx::kRing;
@@ -729,8 +734,14 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
         out->triangles = h.triangles; out->materials = h.materials; out->light_fetches = h.light_fetches;
         out->pixels = h.pixels;
 #ifdef RZ_PROF
-        unsigned long long pr[32];
+        unsigned long long pr[128];
         RZ_HIP(c, hipMemcpy(pr, static_cast<char*>(c->dCounters.p) + sizeof(DevCounters), sizeof pr, hipMemcpyDeviceToHost));
+        for (int r = 0; r < 8; ++r) {       // per query round of a path: 0 primary, 1-2 shadow, 3 first bounce, ...
+            const unsigned long long* q = pr + 32 + 11 * r;
+            auto avg = [](unsigned long long l, unsigned long long e) { return e ? (double)l / (double)e : 0.0; };
+            fprintf(stderr, "[rz_prof] round %d: queries %10llu x %4.1f lanes | descend steps %11llu x %4.1f (uniform %11llu) | triangle tests %11llu x %4.1f | instance entries %10llu x %4.1f | trace wave-cycles %llu\n",
+                    r, q[8], avg(q[9], q[8]), q[0], avg(q[1], q[0]), q[6], q[2], avg(q[3], q[2]), q[4], avg(q[5], q[4]), q[10]);
+        }
         dump_wave_log(use_samples(c) ? (int)std::min<long long>(c->lastGrid, 1 << 17) : K.nLocalTiles);
         static const char* namesPx[] = {"blas loop iter", "leaf branch", "triangle test", "internal branch", "tlas pop", "instance enter", "outer iter", "uniform pair"};
         const char** names = namesPx;
@@ -748,7 +759,14 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
 
 extern "C" {
 
-const char* rz_version(void) { return "rayzen_hip 0.2 (gfx950)"; }
+// The hash of the sources and flags this library was built from (rayzen_amd/build.py: source_hash, passed as
+// -DRZ_SOURCE_HASH): lets a benchmark or a test tie the LOADED library to the tree and to a committed counter file.
+#ifndef RZ_SOURCE_HASH
+#define RZ_SOURCE_HASH "unstamped"
+#endif
+static const char rz_stamp[] = "RZSRCHASH:" RZ_SOURCE_HASH;
+const char* rz_source_hash(void) { return rz_stamp + 10; }
+const char* rz_version(void) { return "rayzen_hip 0.3 (gfx950)"; }
 
 int rz_device_count(void) {
     int n = 0;
@@ -1311,6 +1329,13 @@ int rz_debug_read_layout(rz_ctx* c, int which, void* out, size_t bytes, size_t* 
         }
         return RZ_OK;
     });
+}
+
+int rz_debug_last_plan(rz_ctx* c, rz_launch_plan* out) {
+    if (!c || !out) return fail(c, RZ_ERR_INVALID_ARG, "rz_debug_last_plan: null argument");
+    if (!c->timed) return fail(c, RZ_ERR_NOT_READY, "rz_debug_last_plan: nothing has been rendered yet");
+    *out = c->lastPlan;
+    return RZ_OK;
 }
 
 int rz_debug_fail_alloc(rz_ctx* c, int nth) {

@@ -166,6 +166,19 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
 // is at least as good for the compacting launch.)
 __device__ __forceinline__ int slot_x(int l, bool morton) { return morton ? ((l & 1) | ((l >> 1) & 2) | ((l >> 2) & 4)) : (l & 7); }
 __device__ __forceinline__ int slot_y(int l, bool morton) { return morton ? (((l >> 1) & 1) | ((l >> 2) & 2) | ((l >> 3) & 4)) : (l >> 3); }
+#ifdef RZ_PROF
+// per-query-round site counters and trace cycles -> pr[32 + 11 r + k] (k < 10: rp, k == 10: rt of lane 0)
+__device__ __forceinline__ void rz_prof_rounds(const Tally& c, unsigned long long* pr) {
+    for (int r = 0; r < 8; ++r) {
+        for (int k = 0; k < 10; ++k) {
+            unsigned x = c.rp[r][k];
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+            if ((threadIdx.x & 63) == 0 && x) atomicAdd(&pr[32 + 11 * r + k], (unsigned long long)x);
+        }
+        if ((threadIdx.x & 63) == 0 && c.rt[r]) atomicAdd(&pr[32 + 11 * r + 10], c.rt[r]);
+    }
+}
+#endif
 __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
     a.traversals += b.traversals; a.tlas_nodes += b.tlas_nodes; a.tlas_leaf_indices += b.tlas_leaf_indices;
     a.instances += b.instances; a.blas_nodes += b.blas_nodes; a.triangles += b.triangles; a.materials += b.materials;
@@ -173,6 +186,7 @@ __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
 #ifdef RZ_PROF
     for (int k = 0; k < 16; ++k) a.p[k] += b.p[k];
     for (int k = 0; k < 12; ++k) a.t[k] += b.t[k];
+    for (int r = 0; r < 8; ++r) { a.rt[r] += b.rt[r]; for (int k = 0; k < 10; ++k) a.rp[r][k] += b.rp[r][k]; }
 #endif
 }
 
@@ -268,6 +282,9 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
             }
             // (a wave-uniform loop with a predicated body and one exit, not a per-lane `while`: see blas_walk)
             bool anyRun = rz_ballot(P.mode != MODE_DONE) != 0ull;
+#ifdef RZ_PROF
+            c.rnd = 0;
+#endif
             while (anyRun) {
 #ifdef RZ_PROF
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -284,6 +301,8 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
                 }
 #ifdef RZ_PROF
                 tTrace += t2 - t1; tAdv += __builtin_amdgcn_s_memtime() - t2;
+                c.rt[c.rnd & 7] += t2 - t1;
+                if (c.rnd < 7) ++c.rnd;
 #endif
                 anyRun = rz_ballot(P.mode != MODE_DONE) != 0ull;
             }
@@ -362,10 +381,22 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
                 }
                 // (a per-lane loop here: as a wave-uniform loop with a predicated body, which pays in the opaque variant, this
                 //  one lost 3 % -- 26.1 -> 27.0 ms on the glass + mirror scene)
+#ifdef RZ_PROF
+                c.rnd = 0;
+#endif
                 while (P.mode != MODE_DONE) {
                     HitRec h;
+#ifdef RZ_PROF
+                    RZ_SITE(c, 6);
+                    const unsigned long long tq0_ = __builtin_amdgcn_s_memtime();
+                    const bool found = trace_closest<false, OVF>(K, P.o, P.d, h, bstk, c);
+                    c.rt[c.rnd & 7] += __builtin_amdgcn_s_memtime() - tq0_;
+                    if (c.rnd < 7) ++c.rnd;
+                    advance<false, true>(K, P, found, h, c);
+#else
                     const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, COUNT ? att : c);
                     advance<COUNT, true>(K, P, found, h, COUNT ? att : c);
+#endif
                 }
                 if (run) {
                     const int slot = nextSlot;
@@ -444,6 +475,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
         unsigned long long* pr = reinterpret_cast<unsigned long long*>(K.counters + 1);
         for (int k = 0; k < 16; ++k) if (c.p[k]) atomicAdd(&pr[k], (unsigned long long)c.p[k]);
         if (lane == 0) { atomicAdd(&pr[17], tTrace); atomicAdd(&pr[18], tAdv); atomicAdd(&pr[19], c.t[0]); atomicAdd(&pr[20], c.t[1]); atomicAdd(&pr[21], c.t[2]); for (int k = 3; k < 10; ++k) atomicAdd(&pr[19 + k], c.t[k]); }
+        rz_prof_rounds(c, pr);
     }
 #endif
     if (COUNT) {
@@ -557,12 +589,25 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
         // (one exit, at the end of the body: see blas_walk)
         bool run = P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= stopBounce);
         bool anyRun = rz_ballot(run) != 0ull;
+#ifdef RZ_PROF
+        c.rnd = phase2 ? (P.bounce + 2 < 7 ? P.bounce + 2 : 7) : 0;
+#endif
         while (anyRun) {
             if (run) {
                 HitRec h;
+#ifdef RZ_PROF
+                RZ_SITE(c, 6);
+                const unsigned long long tq0_ = __builtin_amdgcn_s_memtime();
+#endif
                 const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, c);
+#ifdef RZ_PROF
+                c.rt[c.rnd & 7] += __builtin_amdgcn_s_memtime() - tq0_;
+#endif
                 advance<COUNT, false>(K, P, found, h, c);
             }
+#ifdef RZ_PROF
+            if (c.rnd < 7) ++c.rnd;
+#endif
             run = P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= stopBounce);
             anyRun = rz_ballot(run) != 0ull;
         }
@@ -682,6 +727,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
         unsigned long long* pr = reinterpret_cast<unsigned long long*>(K.counters + 1);
         for (int k = 0; k < 16; ++k) if (c.p[k]) atomicAdd(&pr[k], (unsigned long long)c.p[k]);
         if (lane == 0) for (int k = 0; k < 12; ++k) atomicAdd(&pr[19 + k], c.t[k]);
+        rz_prof_rounds(c, pr);
 #endif
     }
     __syncthreads();        // the next claim overwrites the scratch

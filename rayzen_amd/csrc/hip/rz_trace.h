@@ -42,12 +42,17 @@ struct Tally {          // per-thread counts of the REFERENCE algorithm's memory
         samples;
 #ifdef RZ_PROF          // diagnostic build only: where do the lanes of a wave spend their iterations?
     unsigned p[16];
+    int rnd;                    // which closest-hit query of its path this lane is in (0 primary, 1-2 shadow, 3.. bounces), capped at 7
+    unsigned rp[8][10];         // per query round: wave-execs / lanes of [0,1] descend steps [2,3] triangle tests [4,5] instance entries [6,7] uniform-pair steps [8,9] queries
+    unsigned long long rt[8];   // per query round: wave cycles inside trace_closest (lane 0's clock)
     unsigned long long t[12];   // ([4] / [9]: phase 1 / pool rounds of a compacting claim, [10] pool rounds, [11] paths in them)   wave cycles (s_memtime): [0] descend loops, [1] leaf phases, [2] whole BLAS walks; rz_path.h advance(): [3] sky, [4] hit bookkeeping, [5] start_light, [6] shade_light, [7] scatter, [8] of it the hemisphere direction, [9] shadow-step bookkeeping
 #endif
 };
 #ifdef RZ_PROF
 // slot 2k counts wave-level executions of a site (added by the first active lane), slot 2k+1 the active lanes
-#define RZ_SITE(c, k) do { (c).p[2 * (k) + 1] += 1u; if (__lane_id() == (unsigned)(__ffsll((long long)rz_ballot(1)) - 1)) (c).p[2 * (k)] += 1u; } while (0)
+#define RZ_SITE(c, k) do { const bool first_ = __lane_id() == (unsigned)(__ffsll((long long)rz_ballot(1)) - 1); (c).p[2 * (k) + 1] += 1u; if (first_) (c).p[2 * (k)] += 1u; \
+        constexpr int rs_ = (k) == 3 ? 0 : (k) == 2 ? 1 : (k) == 5 ? 2 : (k) == 7 ? 3 : (k) == 6 ? 4 : -1; \
+        if (rs_ >= 0) { (c).rp[(c).rnd & 7][2 * (rs_ < 0 ? 0 : rs_) + 1] += 1u; if (first_) (c).rp[(c).rnd & 7][2 * (rs_ < 0 ? 0 : rs_)] += 1u; } } while (0)
 #else
 #define RZ_SITE(c, k) do { } while (0)
 #endif

@@ -219,6 +219,12 @@ class Renderer:
         """Test hook: the nth host allocation site reached from now on throws std::bad_alloc inside the library."""
         self._check(self._L.rz_debug_fail_alloc(self._c, int(nth)), "rz_debug_fail_alloc")
 
+    def debug_last_plan(self):
+        """Test hook: how the last render call was launched (rz_launch_plan as a dict)."""
+        lp = _lib.LaunchPlan()
+        self._check(self._L.rz_debug_last_plan(self._c, C.byref(lp)), "rz_debug_last_plan")
+        return {n: int(getattr(lp, n)) for n, _ in _lib.LaunchPlan._fields_ if n != "reserved"}
+
     def debug_read_layout(self, which):
         """Test hook: the device scene layout as raw bytes (0: DevPair[], 1: DevTri[])."""
         need = C.c_size_t(0)

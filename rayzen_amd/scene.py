@@ -379,3 +379,28 @@ def stress_scene(n=289, aspect=16.0 / 9.0, blas_builder=None):
     s.name = f"stress{12 * n * n}"
     s.set_blas_builder(blas_builder)
     return s.build()
+
+
+def reference_scene(aspect=800.0 / 600.0, mesh_n=9):
+    """RayZen's own scene (RayZen/src/main.cpp:331-384): camera (0, 0, 3) looking down -z, fov 70; the five materials and
+    two lights of main.cpp:342-357; seven GameObjects, each with its OWN mesh (main.cpp:360-374 loads one Mesh per object,
+    so nothing is shared): the cube floor scaled (8, .5, 8) at y = -3, five ~1 k-triangle meshes -- materials 1 (green
+    metal), 2 (mirror), 0, 0 and 3 (GLASS, scaled 1.2) -- and one EMPTY mesh (`car.obj` is absent from the reference's
+    meshes/, Mesh.cpp:8-11 logs an error and leaves the mesh empty).  monkey.obj (968 triangles) cannot travel to the GPU
+    box, so the stand-in is the 12 * mesh_n^2 = 972-triangle blob at Suzanne's size."""
+    s = Scene(camera=Camera(position=(0.0, 0.0, 3.0), target=(0.0, 0.0, -1.0), aspect=aspect))
+    I = identity()
+    floor = s.add_mesh(make_cube(0))
+    monkey = lambda mat, seed: s.add_mesh(make_blob(mesh_n, 1.0, mat, seed=seed))
+    a, b = monkey(1, 1), monkey(2, 2)
+    car = s.add_mesh(np.zeros(0, TRIANGLE))
+    c, d, glass = monkey(0, 3), monkey(0, 4), monkey(3, 5)
+    s.add_object(floor, translate(scale(I, (8.0, 0.5, 8.0)), (0.0, -3.0, 0.0)))
+    s.add_object(a, translate(I, (-4.0, 0.0, 0.0)))
+    s.add_object(b, translate(I, (4.0, 0.0, 0.0)))
+    s.add_object(car, translate(I, (0.0, 0.0, 0.0)))
+    s.add_object(c, translate(I, (0.0, 0.0, -4.0)))
+    s.add_object(d, translate(I, (0.0, 0.0, 4.0)))
+    s.add_object(glass, translate(scale(I, (1.2, 1.2, 1.2)), (2.5, 0.8, 2.5)))
+    s.name = f"rayzen-main-scene(7 objects, 12+5x{12 * mesh_n * mesh_n} tris)"
+    return s.build()

@@ -22,7 +22,15 @@ def _built():
     rzo.build()
     from rayzen_amd import build
     build.build_host()
-    build.build_hip()       # a no-op when the .so is newer than every source it is built from
+    build.build_hip()       # a no-op when the library in the tree carries the hash of these very sources and flags
+    # the library the suite is about to LOAD must be the one built from this tree: a stale .so beside fresh sources (or
+    # an A/B variant left in RAYZEN_HIP_SO) would make every parity claim below a claim about other code
+    from rayzen_amd import _lib
+    loaded, tree = _lib.hip().rz_source_hash().decode(), build.source_hash()
+    if os.environ.get("RAYZEN_HIP_SO"):
+        print(f"[conftest] RAYZEN_HIP_SO override: testing {_lib.HIP_SO} (source hash {loaded[:16]}, tree {tree[:16]})", file=sys.stderr)
+    else:
+        assert loaded == tree, f"{_lib.HIP_SO} was built from other sources ({loaded[:16]}) than this tree ({tree[:16]})"
     yield
 
 

@@ -59,6 +59,19 @@ def test_versions():
     assert _lib.host().rzh_version()
 
 
+def test_library_carries_the_hash_of_the_sources_it_was_built_from():
+    """the loaded library, the file on disk and the tree agree on one source hash (what bench.py checks
+    before it prints another run's hardware counters)."""
+    from rayzen_amd import build
+    h = _lib.hip().rz_source_hash().decode()
+    assert re.fullmatch(r"[0-9a-f]{64}", h), h
+    assert build.stamped_hash(_lib.HIP_SO) == h
+    if not os.environ.get("RAYZEN_HIP_SO"):
+        assert h == build.source_hash()
+    assert build.source_hash(("-DRZ_PROF",)) != build.source_hash()      # flags are part of the identity
+    assert build.stamped_hash(os.path.join(ROOT, "no", "such.so")) is None
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     """Without a HIP device rz_create must fail; the Python wrapper raises (there is no CPU render path)."""
     import torch

@@ -84,25 +84,62 @@ def test_c4_full_size_sixteen_instances_dynamic():
     r.close()
 
 
-def test_c5_full_size_one_million_triangles_4k_overflow_columns():
-    """configs[4]: 1 002 264 triangles (BLAS depth 21), 3840x2160, 8 bounces.  64 spp instead of 128 keeps the test
-    short but takes the same launch: persistent waves, and the deep tree keeps only a window of its traversal stack
-    in LDS, the rest in global overflow columns (the path under test)."""
-    from rayzen_amd.renderer import Renderer
-    W, H, spp, b = 3840, 2160, 64, 8
-    r = Renderer(0)
+def _c5_scene(r, W, H):
     sc = S.stress_scene(n=289, aspect=W / H, blas_builder=r)     # BLAS built on the device (same bytes as the host's)
     assert sc.arrays[S.BIND_TRIANGLES].shape[0] == 12 + 12 * 289 * 289
     assert sc.max_blas_depth >= 20
-    gpu = hip_render(sc, W, H, spp, b, renderer=r)
-    assert r.last_kernel_name() == "rz_render_samples"
-    r.close()
+    return sc
+
+
+def _c5_check(sc, gpu, W, H, spp, b):
     assert np.isfinite(gpu).all() and (gpu >= 0).all() and (gpu[..., 3] == spp).all()
     bands = (600, 1080, 1500)
     ref = _oracle_bands(sc, W, H, spp, b, bands, rows=4)
     for y0 in bands:
         g, o = gpu[y0:y0 + 4], ref[y0:y0 + 4]
         assert (g.view(np.uint32) == o.view(np.uint32)).all(), mismatch_report(g, o)
+
+
+def test_c5_full_size_one_million_triangles_4k_at_its_stated_128_spp():
+    """configs[4] as BASELINE.json states it: 1 002 264 triangles (BLAS depth 21), 3840x2160, 128 spp, 8 bounces -- the
+    whole frame on one GPU.  128 spp = two 64-sample batches per pixel, and at 16.6 M (pixel, batch) units the launch
+    takes the persistent grid with 16-unit compacting claims of 8 pixels x 2 batches (rz_kernels.hip:
+    plan_render_samples) -- a claim shape no smaller test takes; the launch plan is read back and asserted.  The deep
+    tree's 20 stack entries fit the LDS window since the TLAS walk keeps no stack: no overflow columns here (the next
+    test forces them).  Three 4-row oracle bands at 128 spp are 5.9 M oracle paths.
+    Reference semantics: fragment_shader.glsl:668-773."""
+    from rayzen_amd.renderer import Renderer
+    W, H, spp, b = 3840, 2160, 128, 8
+    r = Renderer(0)
+    sc = _c5_scene(r, W, H)
+    gpu = hip_render(sc, W, H, spp, b, renderer=r)
+    assert r.last_kernel_name() == "rz_render_samples"
+    plan = r.debug_last_plan()
+    r.close()
+    assert plan["batches_per_pixel"] == 2 and plan["pixels_per_wave"] == 1
+    assert plan["claim_units"] == 16 and plan["per_claim"] == 8, plan          # 8 pixels x 2 batches per claim
+    assert plan["groups"] == W * H and plan["grid"] < plan["groups"] // 64      # persistent: far fewer waves than pixels
+    assert plan["overflow_entries"] == 0 and plan["lds_stack_entries"] == sc.max_blas_depth - 1 and plan["transparent"] == 0
+    _c5_check(sc, gpu, W, H, spp, b)
+
+
+def test_c5_full_size_with_the_stack_overflow_columns_forced(monkeypatch):
+    """The OVF = true instantiation at full size: with the LDS window of the BLAS stack forced down to 6 entries the
+    1 M-triangle mesh keeps the other 14 levels of its traversal stack in the global overflow columns of the resident
+    waves (rz_trace.h: push_entry / pop_entry).  64 spp: one batch per pixel, and at 8.3 M units the launch takes 16-unit
+    claims of 16 pixels -- same frame size, same tree, bit-identical to the oracle bands."""
+    from rayzen_amd.renderer import Renderer
+    W, H, spp, b = 3840, 2160, 64, 8
+    r = Renderer(0)
+    sc = _c5_scene(r, W, H)
+    monkeypatch.setenv("RZ_BLAS_STACK_WINDOW", "6")
+    gpu = hip_render(sc, W, H, spp, b, renderer=r)
+    plan = r.debug_last_plan()
+    monkeypatch.delenv("RZ_BLAS_STACK_WINDOW")
+    r.close()
+    assert plan["lds_stack_entries"] == 6 and plan["overflow_entries"] == sc.max_blas_depth - 1 - 6, plan
+    assert plan["per_claim"] == 16 and plan["claim_units"] == 16 and plan["batches_per_pixel"] == 1, plan
+    _c5_check(sc, gpu, W, H, spp, b)
 
 
 def test_nan_ior_on_a_glass_material_terminates_and_matches():
