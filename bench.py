@@ -7,10 +7,16 @@
 One "step" = one pass of the hot path over one frame of synthetic input: BASELINE.json configs[1], the
 ~69k-triangle "bunny" scene (procedural stand-in, see rayzen_amd/scene.py) at 1920x1080, 4 bounces, 64 samples per
 pixel per GPU.  At N > 1 the frame's 8x8-pixel tiles are dealt round-robin to the ranks and ONE RCCL reduce(SUM) per
-step lands the frame on rank 0 -- both through the C-ABI's multi-GPU group (include/rayzen_hip.h: rz_group_*; one
-process per GPU, ncclCommInitRank with an id broadcast over torch.distributed, the reduce enqueued on the render
-stream).  Default N > 1 workload: every rank renders 64*N spp of its own pixels (per-GPU work constant: "weak");
-`--spp-total T` fixes the frame at T spp instead ("strong"; `--spp-total 256` at N = 8 is BASELINE configs[2]).
+step lands the frame on rank 0 -- both through the C-ABI's multi-GPU group (include/rayzen_hip.h: rz_group_*), the
+reduce enqueued on each member's render stream.  Two ways to start it:
+  * `python bench.py --gpus N` as ONE plain process (no launcher, WORLD_SIZE unset): rz_group_create(N) -- N contexts on
+    the node's first N devices and their communicators from ncclCommInitAll; nothing is re-executed, no torch.distributed;
+  * under torch.distributed.run (WORLD_SIZE = N): one process per GPU, rz_group_create_rank with an id broadcast over
+    torch.distributed (ncclCommInitRank).
+The JSON says which ran (`config.parallelism`), how many ranks RCCL saw (`rccl_ranks`) and what the reduce cost
+(`reduce_ms`: HIP events around it on the root's stream).  Default N > 1 workload: every rank renders 64*N spp of its own
+pixels (per-GPU work constant: "weak"); `--spp-total T` fixes the frame at T spp instead ("strong"; `--spp-total 256` at
+N = 8 is BASELINE configs[2], the C3 line).
 Scene buffers are resident in HBM before the timed region; nothing is skipped inside it.
 
 Rank 0 prints ONE JSON line.  `value` = total camera paths (pixels x spp) / wall time of the K timed steps (max over
@@ -65,7 +71,7 @@ INST_COUNTERS = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LD
                  "SQ_INSTS_VMEM_WR", "SQ_INSTS_BRANCH")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -90,40 +96,59 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (default: min(16, usable cores) = the box's CPU share)")
     ap.add_argument("--cpu-bands", type=int, default=36, help="oracle sample: this many 8-row bands of the frame")
     ap.add_argument("--cpu-full-frame", action="store_true", help="also time the oracle on the WHOLE frame (about 6 s on 16 threads)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def main():
-    a = parse()
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    use_group = world > 1 and a.reduce == "group"
-    use_nccl = world > 1 and a.reduce in ("group", "torch")
-    dev_index = local_rank if (world == 1 or use_nccl) else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+def launch_mode(gpus, environ):
+    """How `--gpus N` is served: 'single' (N = 1), 'ranks' (a launcher started one process per GPU: WORLD_SIZE = N), or
+    'local-group' (ONE plain process drives N devices through rz_group_create -- what `python3 bench.py --gpus N` gets
+    when nothing launched it; no process is ever re-executed)."""
+    world = int(environ.get("WORLD_SIZE", "1"))
     if world > 1:
+        if world != gpus:
+            raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}")
+        return "ranks"
+    return "local-group" if gpus > 1 else "single"
+
+
+def main(argv=None):
+    a = parse(argv)
+    import numpy as np
+
+    mode = launch_mode(a.gpus, os.environ)
+    world = a.gpus
+    rank = int(os.environ.get("RANK", "0")) if mode == "ranks" else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if mode == "ranks" else 0
+
+    from rayzen_amd import _lib as rzlib
+    from rayzen_amd import build as rzbuild
+    from rayzen_amd import dist as rzdist
+    from rayzen_amd import scene as S
+    from rayzen_amd.renderer import Renderer, algorithmic_bytes, frame_params
+
+    ndev = rzlib.hip().rz_device_count()
+    if ndev <= 0:
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if mode == "local-group" and a.reduce != "group":
+        raise SystemExit("--reduce torch / torch-gloo need one process per GPU: start bench.py with torch.distributed.run")
+    if mode == "local-group" and ndev < world:
+        raise SystemExit(f"--gpus {world} but only {ndev} HIP device(s) are visible to this process")
+
+    torch = dist = dev = None
+    use_group = world > 1 and a.reduce == "group"
+    use_nccl = mode == "ranks" and a.reduce in ("group", "torch")
+    dev_index = 0
+    if mode == "ranks":
+        import torch
+        import torch.distributed as dist
+        dev_index = local_rank if use_nccl else local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if use_nccl:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # group mode: barrier + max-over-ranks only
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-
-    from rayzen_amd import build as rzbuild
-    from rayzen_amd import dist as rzdist
-    from rayzen_amd import scene as S
-    from rayzen_amd.renderer import Renderer, algorithmic_bytes, frame_params
 
     W, H, bounces = a.width, a.height, a.bounces
     spp_total = a.spp_total if a.spp_total > 0 else a.spp * world   # every rank renders ALL samples of its own pixels
@@ -135,54 +160,62 @@ def main():
     fp = frame_params(sc.camera, W, H, len(sc.lights), bounces, spp_total, 0, rank, world)
 
     group = None
-    if use_group:
-        # rank 0 makes the communicator id, everybody receives it over the launcher's own process group
+    if mode == "local-group":
+        # ONE process, N devices: the library makes the contexts and the communicators (ncclCommInitAll)
+        group = rzdist.Group.create(world, None, flags)
+    elif use_group:
+        # Two steps, so that a rank which cannot even bind RCCL or make its context never leaves the others waiting inside
+        # ncclCommInitRank: (1) every rank probes, all agree; (2) rank 0 makes the communicator id, everybody receives it over
+        # the launcher's own process group and joins.
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        try:
+            rzdist.rccl_version()
+            Renderer(dev_index, flags).close()
+        except Exception as e:
+            print(f"[bench] rank {rank}: cannot bind RCCL / make a context ({e}); falling back to torch.distributed.reduce", file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         uid = torch.zeros(129, dtype=torch.uint8, device=dev)       # 128 id bytes + 1 "rank 0 could make it" flag
-        if rank == 0:
+        if int(ok.item()) == 1 and rank == 0:
             try:
                 uid[:128].copy_(torch.frombuffer(bytearray(rzdist.unique_id()), dtype=torch.uint8))
                 uid[128] = 1
             except Exception as e:
                 print(f"[bench] rz_group_unique_id failed ({e}); falling back to torch.distributed.reduce", file=sys.stderr)
         dist.broadcast(uid, 0)
-        ok = torch.ones(1, dtype=torch.int32, device=dev)
-        if int(uid[128].item()) == 1:
-            try:
-                group = rzdist.Group.create_rank(dev_index, rank, world, bytes(uid[:128].cpu().numpy().tobytes()), flags)
-            except Exception as e:       # every rank must take the same way out
-                print(f"[bench] rank {rank}: rz_group_create_rank failed ({e}); falling back to torch.distributed.reduce", file=sys.stderr)
-                ok.zero_()
+        if int(ok.item()) == 1 and int(uid[128].item()) == 1:
+            group = rzdist.Group.create_rank(dev_index, rank, world, bytes(uid[:128].cpu().numpy().tobytes()), flags)
         else:
-            ok.zero_()
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            if group is not None:
-                group.close()
-            group, use_group = None, False
+            use_group = False
     if group is not None:
         group.upload_scene(sc)
         group.set_frame(fp)             # tile_rank / tile_nranks are filled in by the group
-        r = group.member(0)
+        members = [group.member(i) for i in range(group.local_count)]
+        r = members[0]
         accum = frame = None
     else:
         r = Renderer(dev_index, flags)
+        members = [r]
         r.upload_scene(sc)
-        accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)    # zero outside this rank's tiles
-        stream = torch.cuda.Stream(dev)     # the kernels, the reduce and the fences all order on this stream
-        torch.cuda.set_stream(stream)
-        r.set_stream(stream.cuda_stream)
-        r.bind_accum(accum.data_ptr(), accum.numel() * 4)
+        if mode == "ranks":
+            accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)    # zero outside this rank's tiles
+            stream = torch.cuda.Stream(dev)     # the kernels, the reduce and the fences all order on this stream
+            torch.cuda.set_stream(stream)
+            r.set_stream(stream.cuda_stream)
+            r.bind_accum(accum.data_ptr(), accum.numel() * 4)
+            # N > 1 rehearsal: `accum` is this rank's private buffer; each step copies it to `frame` and reduces THAT
+            frame = torch.empty_like(accum)
+        else:
+            accum = frame = None                # one GPU: the context's own accumulation buffer
         r.set_frame(fp)
-        # N > 1 rehearsal: `accum` is this rank's private buffer; each step copies it to `frame` and reduces THAT
-        frame = torch.empty_like(accum) if world > 1 else accum
 
     def step():
         if group is not None:
-            group.render()                  # asynchronous on the member's stream
-            group.reduce(0)                 # ONE ncclReduce(sum) of the 33 MB frame, enqueued behind the kernel
+            group.render()                  # asynchronous on the members' streams
+            group.reduce(0)                 # ONE ncclReduce(sum) of the 33 MB frame per member, enqueued behind its kernel
             return
         r.render()
-        if world > 1:
+        if mode == "ranks":
             frame.copy_(accum)
             if use_nccl:                    # torch path: one RCCL reduce(SUM) of the 33 MB frame
                 rzdist.reduce_accum(frame, dst=0)
@@ -193,37 +226,43 @@ def main():
                     frame.copy_(host)
 
     def fence():
-        # drain this rank's own work first, so that the group's RCCL communicator and torch's (the barrier) are never
+        # drain this process's own work first, so that the group's RCCL communicator and torch's (the barrier) are never
         # in flight together; then the barrier, then the device once more (the barrier itself runs on the GPU)
         if group is not None:
             group.sync()
-        torch.cuda.synchronize(dev)
-        if world > 1:
+        else:
+            r.sync()
+        if mode == "ranks":
+            torch.cuda.synchronize(dev)
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    # untimed instrumented launch: exact algorithmic unit counts of THIS rank's launch
-    counters = r.render_counted()
+    # untimed instrumented launches: exact algorithmic unit counts of this process's launches (all members of a local group)
+    counters = None
+    for m in members:
+        cm = m.render_counted()
+        counters = cm if counters is None else {k: counters[k] + cm[k] for k in cm}
     alg_bytes = algorithmic_bytes(counters)
-    if group is not None:
-        group.sync()
-    torch.cuda.synchronize(dev)
+    fence()
 
     for _ in range(a.warmup):
         step()
     fence()
-    r.render_history_ms()               # drain: only the timed launches remain in the event ring
+    for m in members:
+        m.render_history_ms()           # drain: only the timed launches remain in the event rings
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     fence()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    # GPU duration of each timed launch: HIP event pairs recorded on the launch stream inside the timed region
-    kernel_ms = r.render_history_ms()
-    kms = float(np.mean(kernel_ms))
+    # GPU duration of each timed launch: HIP event pairs recorded on the launch stream inside the timed region (of a local
+    # group: the member whose launches took longest)
+    member_ms = [float(np.mean(m.render_history_ms())) for m in members]
+    kms = max(member_ms)
+    reduce_ms = group.last_reduce_ms() if group is not None else None
 
-    if world > 1:
+    if mode == "ranks":
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if use_nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -245,18 +284,30 @@ def main():
                    "camera": {"position": [float(x) for x in cam.position], "target_dir": [float(x) for x in cam.target],
                               "fov_deg": cam.fov}, "mesh_radius": 2.8, "mesh_centre": [0.0, 2.0, 0.0],
                    "floor": "cube scaled (8, 0.5, 8) at y = -3 (main.cpp:378)",
-                   "parallelism": f"tiles8x8-roundrobin-x{world}" + (("+rz_group-rccl-reduce" if use_group else ("+torch-rccl-reduce" if use_nccl else "+gloo-reduce(rehearsal)")) if world > 1 else "")},
+                   "parallelism": f"tiles8x8-roundrobin-x{world}" + ((("+rz_group-rccl-reduce(" + ("one process, ncclCommInitAll" if mode == "local-group" else "one process per GPU, ncclCommInitRank") + ")")
+                                                                     if use_group else ("+torch-rccl-reduce" if use_nccl else "+gloo-reduce(rehearsal)")) if world > 1 else "")},
     }
+    if world > 1:
+        # what RCCL saw: the size of the library's communicator (0: the reduce went through torch.distributed instead), and
+        # the GPU time of the LAST timed step's reduce by HIP events on the root's stream -- it starts when the root's own
+        # kernel ends, so it holds the wait for the slowest rank as well as the 33-MB transfer
+        out["rccl_ranks"] = group.size if group is not None else 0
+        out["launch"] = mode
+        if reduce_ms is not None:
+            out["reduce_ms"] = round(reduce_ms[0] if reduce_ms[0] >= 0 else reduce_ms[1], 3)
+            out["reduce_ms_note"] = "HIP events around rz_group_reduce on the root member's stream (last timed step)"
+        out["kernel_ms_per_member"] = [round(x, 3) for x in member_ms]
     if rank == 0:
         if group is not None:
-            final = torch.from_numpy(group.read_frame())
+            final = group.read_frame()
+        elif mode == "ranks":
+            final = frame.cpu().numpy()
         else:
-            final = frame
+            final = r.read_accum()
         # size-independent check of the sharding + reduce: every pixel of the final frame received exactly
         # spp_total samples (a pixel rendered twice or not at all by the tile deal would show here)
-        cnt = final[..., 3]
-        out["frame_check"] = {"every_pixel_has_spp_total_samples": bool((cnt == float(spp_total)).all().item()),
-                              "finite_and_nonnegative": bool((torch.isfinite(final).all() & (final >= 0).all()).item())}
+        out["frame_check"] = {"every_pixel_has_spp_total_samples": bool((final[..., 3] == float(spp_total)).all()),
+                              "finite_and_nonnegative": bool(np.isfinite(final).all() and (final >= 0).all())}
         nl = max(1, len(sc.lights))
         kernel_s = kms * 1e-3
         out["work"] = {"camera_paths_per_launch": counters["samples"],
@@ -334,7 +385,7 @@ def main():
             rows += 8
             bands.append(y0)
         cpu_samples = rows * W * a.spp
-        gpu = final.cpu().numpy()       # last timed frame (sample_base 0 each step: a complete frame)
+        gpu = final                     # last timed frame (sample_base 0 each step: a complete frame)
         err, same, tot = 0.0, 0, 0
         for y0 in bands:
             g, o = gpu[y0:y0 + 8], ref[y0:y0 + 8]
@@ -361,7 +412,7 @@ def main():
         group.close()
     else:
         r.close()
-    if world > 1:
+    if mode == "ranks":
         dist.destroy_process_group()
 
 

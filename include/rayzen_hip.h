@@ -332,6 +332,11 @@ int rz_group_render(rz_group* g);
  * buffer is overwritten, so frames can be continued with sample_base > 0). */
 int rz_group_reduce(rz_group* g, int root);
 int rz_group_sync(rz_group* g);                                 /* glFinish on every local member */
+/* GPU time of the last rz_group_reduce, from HIP events recorded on each local member's stream just before and just
+ * after its share of the collective was enqueued: *root_ms on the root member (-1 when the root lives in another
+ * process), *max_ms the longest over this process's members.  A member's interval starts when its render kernel ends,
+ * so it contains the wait for the slowest rank as well as the transfer.  Synchronises the members' streams. */
+int rz_group_last_reduce_ms(rz_group* g, float* root_ms, float* max_ms);
 /* Copy the reduced frame (RGBA32F, row 0 = bottom) to host memory.  Only valid in the process that owns `root` of the
  * last rz_group_reduce; RZ_ERR_NOT_READY elsewhere.  Synchronises that member's stream. */
 int rz_group_read_frame(rz_group* g, float* rgba, size_t bytes);

@@ -120,6 +120,8 @@ int rzo_build_blas(const rzo_triangle* tris, int n, rzo_node* nodes_out, int32_t
 int rzo_build_tlas(const rzo_node* roots, int n, rzo_node* nodes_out, int32_t* idx_out, int* n_idx_out);
 /* main.cpp:974-993: world AABB of a BLAS root box under a column-major transform. */
 void rzo_world_bounds(const rzo_node* root, const float transform[16], float bmin[3], float bmax[3]);
+/* glm::inverse(mat4) as main.cpp:1001, 1058, 1151 call it: GLM 0.9.9.8 compute_inverse<4,4>, column-major in and out. */
+void rzo_mat4_inverse(const float m[16], float out[16]);
 /* Mesh.cpp:6-50.  Two-pass: tris_out NULL => returns the triangle count; else fills up to cap. -1: cannot open. */
 int rzo_load_obj(const char* path, int materialIndex, rzo_triangle* tris_out, int cap);
 

@@ -10,6 +10,7 @@
  *                       (findSAHSplit), 99-175 (buildBLAS, SAH branch)
  *   rzo_build_tlas   <- RayZen/src/BVH.cpp:178-240
  *   rzo_world_bounds <- RayZen/src/main.cpp:974-993
+ *   rzo_mat4_inverse <- glm::inverse as called at RayZen/src/main.cpp:1001, 1058, 1151 (GLM 0.9.9.8's published algorithm)
  *   rzo_load_obj     <- RayZen/src/Mesh.cpp:6-50
  *
  * Deliberately the reference's O(N log^2 N) algorithm (re-sort at every
@@ -215,7 +216,11 @@ int rzo_build_tlas(const rzo_node* roots, int n, rzo_node* nodes, int32_t* idx_o
     return nn;
 }
 
-/* main.cpp:974-993: 8 corners, tc = vec3(transform * vec4(corner, 1)), init +-1e30 */
+/* main.cpp:974-993: 8 corners, tc = vec3(transform * vec4(corner, 1)), init +-1e30.
+ * glm's mat4 * vec4 (GLM 0.9.9.8, glm/detail/type_mat4x4.inl -- GLM is a third-party, un-vendored, version-unpinned
+ * dependency of the reference, RayZen/CMakeLists.txt:16-18, absent from this image; its published algorithm is restated):
+ * Mul0 = m[0]*v.x, Mul1 = m[1]*v.y, Add0 = Mul0 + Mul1, Mul2 = m[2]*v.z, Mul3 = m[3]*v.w, Add1 = Mul2 + Mul3,
+ * result = Add0 + Add1 -- the column products are added PAIRWISE. */
 void rzo_world_bounds(const rzo_node* root, const float m[16], float bmin[3], float bmax[3]) {
     float cx[2] = {root->bmin[0], root->bmax[0]}, cy[2] = {root->bmin[1], root->bmax[1]},
           cz[2] = {root->bmin[2], root->bmax[2]};
@@ -223,14 +228,64 @@ void rzo_world_bounds(const rzo_node* root, const float m[16], float bmin[3], fl
     /* corner order of main.cpp:976-983: x outer, y middle, z inner */
     for (int ix = 0; ix < 2; ++ix) for (int iy = 0; iy < 2; ++iy) for (int iz = 0; iz < 2; ++iz) {
         float x = cx[ix], y = cy[iy], z = cz[iz];
-        /* glm mat4*vec4: ((c0*x + c1*y) + c2*z) + c3*w, w = 1 */
-        b3 tc = B3(((m[0] * x + m[4] * y) + m[8] * z) + m[12] * 1.0f,
-                   ((m[1] * x + m[5] * y) + m[9] * z) + m[13] * 1.0f,
-                   ((m[2] * x + m[6] * y) + m[10] * z) + m[14] * 1.0f);
+        float t[3];
+        for (int r = 0; r < 3; ++r) {
+            float add0 = m[r] * x + m[4 + r] * y;
+            float add1 = m[8 + r] * z + m[12 + r] * 1.0f;
+            t[r] = add0 + add1;
+        }
+        b3 tc = B3(t[0], t[1], t[2]);
         mn = min3(mn, tc); mx = max3(mx, tc);
     }
     bmin[0] = mn.x; bmin[1] = mn.y; bmin[2] = mn.z;
     bmax[0] = mx.x; bmax[1] = mx.y; bmax[2] = mx.z;
+}
+
+/* glm::inverse(mat4) -- main.cpp:1001, 1058, 1151 fill BVHInstance::inverseTransform with it.  GLM 0.9.9.8,
+ * glm/detail/func_matrix.inl, compute_inverse<4, 4>, written out scalar by scalar (GLM's m[c][r] is m[4*c + r]):
+ * Coef00..23, Fac0..5, Vec0..3, Inv0..3, SignA / SignB, Row0, Dot0, Dot1 = (x + y) + (z + w), times 1 / Dot1. */
+void rzo_mat4_inverse(const float m[16], float out[16]) {
+#define E(c, r) m[4 * (c) + (r)]
+    float Coef00 = E(2,2) * E(3,3) - E(3,2) * E(2,3);
+    float Coef02 = E(1,2) * E(3,3) - E(3,2) * E(1,3);
+    float Coef03 = E(1,2) * E(2,3) - E(2,2) * E(1,3);
+    float Coef04 = E(2,1) * E(3,3) - E(3,1) * E(2,3);
+    float Coef06 = E(1,1) * E(3,3) - E(3,1) * E(1,3);
+    float Coef07 = E(1,1) * E(2,3) - E(2,1) * E(1,3);
+    float Coef08 = E(2,1) * E(3,2) - E(3,1) * E(2,2);
+    float Coef10 = E(1,1) * E(3,2) - E(3,1) * E(1,2);
+    float Coef11 = E(1,1) * E(2,2) - E(2,1) * E(1,2);
+    float Coef12 = E(2,0) * E(3,3) - E(3,0) * E(2,3);
+    float Coef14 = E(1,0) * E(3,3) - E(3,0) * E(1,3);
+    float Coef15 = E(1,0) * E(2,3) - E(2,0) * E(1,3);
+    float Coef16 = E(2,0) * E(3,2) - E(3,0) * E(2,2);
+    float Coef18 = E(1,0) * E(3,2) - E(3,0) * E(1,2);
+    float Coef19 = E(1,0) * E(2,2) - E(2,0) * E(1,2);
+    float Coef20 = E(2,0) * E(3,1) - E(3,0) * E(2,1);
+    float Coef22 = E(1,0) * E(3,1) - E(3,0) * E(1,1);
+    float Coef23 = E(1,0) * E(2,1) - E(2,0) * E(1,1);
+    float Fac0[4] = {Coef00, Coef00, Coef02, Coef03}, Fac1[4] = {Coef04, Coef04, Coef06, Coef07};
+    float Fac2[4] = {Coef08, Coef08, Coef10, Coef11}, Fac3[4] = {Coef12, Coef12, Coef14, Coef15};
+    float Fac4[4] = {Coef16, Coef16, Coef18, Coef19}, Fac5[4] = {Coef20, Coef20, Coef22, Coef23};
+    float Vec0[4] = {E(1,0), E(0,0), E(0,0), E(0,0)}, Vec1[4] = {E(1,1), E(0,1), E(0,1), E(0,1)};
+    float Vec2[4] = {E(1,2), E(0,2), E(0,2), E(0,2)}, Vec3[4] = {E(1,3), E(0,3), E(0,3), E(0,3)};
+    static const float SignA[4] = {+1.0f, -1.0f, +1.0f, -1.0f}, SignB[4] = {-1.0f, +1.0f, -1.0f, +1.0f};
+    float Inverse[16];
+    for (int j = 0; j < 4; ++j) {
+        float Inv0 = Vec1[j] * Fac0[j] - Vec2[j] * Fac1[j] + Vec3[j] * Fac2[j];
+        float Inv1 = Vec0[j] * Fac0[j] - Vec2[j] * Fac3[j] + Vec3[j] * Fac4[j];
+        float Inv2 = Vec0[j] * Fac1[j] - Vec1[j] * Fac3[j] + Vec3[j] * Fac5[j];
+        float Inv3 = Vec0[j] * Fac2[j] - Vec1[j] * Fac4[j] + Vec2[j] * Fac5[j];
+        Inverse[0 + j] = Inv0 * SignA[j];
+        Inverse[4 + j] = Inv1 * SignB[j];
+        Inverse[8 + j] = Inv2 * SignA[j];
+        Inverse[12 + j] = Inv3 * SignB[j];
+    }
+    float Dot0x = E(0,0) * Inverse[0], Dot0y = E(0,1) * Inverse[4], Dot0z = E(0,2) * Inverse[8], Dot0w = E(0,3) * Inverse[12];
+    float Dot1 = (Dot0x + Dot0y) + (Dot0z + Dot0w);
+    float OneOverDeterminant = 1.0f / Dot1;
+    for (int k = 0; k < 16; ++k) out[k] = Inverse[k] * OneOverDeterminant;
+#undef E
 }
 
 /* Mesh.cpp:6-50: "v " and "f " lines only; face tokens split at the first '/';

@@ -99,6 +99,8 @@ def lib():
         L.rzo_build_tlas.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.rzo_world_bounds.restype = None
         L.rzo_world_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rzo_mat4_inverse.restype = None
+        L.rzo_mat4_inverse.argtypes = [C.c_void_p, C.c_void_p]
         L.rzo_load_obj.restype = C.c_int
         L.rzo_load_obj.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int]
         _lib = L
@@ -232,6 +234,14 @@ def world_bounds(root, transform):
     mx = np.zeros(3, np.float32)
     lib().rzo_world_bounds(r.ctypes.data, m.ctypes.data, mn.ctypes.data, mx.ctypes.data)
     return mn, mx
+
+
+def mat4_inverse(m):
+    """glm::inverse of a column-major mat4 (16 float32)."""
+    a = np.asarray(m, np.float32).reshape(16).copy()
+    out = np.zeros(16, np.float32)
+    lib().rzo_mat4_inverse(a.ctypes.data, out.ctypes.data)
+    return out
 
 
 def load_obj(path, material_index):

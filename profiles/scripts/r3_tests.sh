@@ -1,0 +1,6 @@
+# the GPU suite in one process, log under gpurun_out/$1
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/$1; mkdir -p $O
+timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1; rc=$?
+tail -15 $O/gpu_tests.log
+exit $rc

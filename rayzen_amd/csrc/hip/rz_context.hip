@@ -143,9 +143,16 @@ int fail(rz_ctx* c, int code, const char* fmt, ...) {
 // std::string growth runs its body through guarded(), which turns std::bad_alloc into RZ_ERR_NO_MEMORY and anything
 // else into RZ_ERR_HIP.  (rz_debug_fail_alloc arms a countdown that makes alloc_point() throw std::bad_alloc at the
 // n-th host allocation site reached -- the test hook that proves the conversion.)
+// It also makes the context's device the calling thread's current one: a context may be driven while another device is
+// current (a group of several devices in one process, rz_group.hip: a member reached through rz_group_ctx), and every
+// hipMalloc, kernel launch and event below would otherwise land on THAT device.
 template <class F>
 int guarded(rz_ctx* c, const char* what, F&& body) {
     try {
+        if (c) {
+            const hipError_t e = hipSetDevice(c->device);
+            if (e != hipSuccess) return fail(c, RZ_ERR_HIP, "%s: hipSetDevice(%d): %s", what, c->device, hipGetErrorString(e));
+        }
         return body();
     } catch (const std::bad_alloc&) {
         return fail(c, RZ_ERR_NO_MEMORY, "%s: out of host memory", what);
@@ -595,6 +602,9 @@ int finalize(rz_ctx* c) {
     }
 }
 
+#ifndef RZ_SPREAD_MIN_INSTANCES
+#define RZ_SPREAD_MIN_INSTANCES 3
+#endif
 #ifndef RZ_CLAIM_STRIDE_PAD
 #define RZ_CLAIM_STRIDE_PAD 0      // extra dwords between the scratch regions of neighbouring resident waves
 #endif
@@ -697,6 +707,16 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     std::memcpy(K.invProj, f.inv_proj, 64);
     std::memcpy(K.camPos, f.cam_pos, 12);
     std::memcpy(K.hemi0, c->hemi0, 12);
+    {
+        const long long nIdx = c->deviceOwnsTlas ? (long long)c->tlasHostCounts[1] : (long long)hostCount<int32_t>(c, RZ_BIND_TLAS_INDICES);
+        K.traceRoundCap = (int)std::min<long long>(0x7fffffff, nIdx + (long long)c->nTlasDfs + 64);
+        // Spread rays are traced lane by lane when they have several instances to spread over: with two (C2: floor + mesh) the
+        // wave-cursor walk's scalar fetches and octant tests are worth more than walking both instances at once.
+        // RZ_SPREAD_MIN_INSTANCES overrides the threshold (0 = never; A/B aid).
+        long long minInst = RZ_SPREAD_MIN_INSTANCES;
+        if (const char* e = std::getenv("RZ_SPREAD_MIN_INSTANCES")) minInst = std::atoll(e);
+        K.spreadTrace = (minInst > 0 && nIdx >= minInst) ? 1 : 0;
+    }
     const size_t perWave = (size_t)K.blasStackCap * 512 + (size_t)K.tlasStackCap * 256 + 4864;
     if (perWave * 4 > 160 * 1024)   // sized for the largest (4-wave) workgroup
         return fail(c, RZ_ERR_BAD_SCENE, "BLAS depth %d needs %zu B of LDS stack per wave; the limit is %d", c->maxBlasDepth, perWave, 40 * 1024);
@@ -749,6 +769,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
             fprintf(stderr, "[rz_prof] %-16s wave-execs %12llu  lanes %14llu  avg active lanes %.1f\n", names[k], pr[2 * k], pr[2 * k + 1], pr[2 * k] ? (double)pr[2 * k + 1] / (double)pr[2 * k] : 0.0);
         fprintf(stderr, "[rz_prof] wave cycles: begin %llu  trace %llu  advance %llu | inside trace: descend loops %llu  leaf phases %llu  whole BLAS walks %llu\n", pr[16], pr[17], pr[18], pr[19], pr[20], pr[21]);
         fprintf(stderr, "[rz_prof] compacting claims: phase 1 (units) %llu  pool rounds %llu wave cycles; %llu rounds with %llu paths = %.1f lanes per round\n", pr[23], pr[28], pr[29], pr[30], pr[29] ? (double)pr[30] / (double)pr[29] : 0.0);
+        fprintf(stderr, "[rz_prof] pool_trace (a claim's pooled queries traced together): %llu wave cycles = T phases %llu + B phases %llu (of which refills %llu); round 7 above = its steps\n", pr[120], pr[121], pr[122], pr[123]);
         fprintf(stderr, "[rz_prof] inside advance: sky %llu  hit %llu  start_light %llu  shade_light %llu  scatter %llu (hemisphere %llu)  shadow step %llu\n", pr[22], pr[23], pr[24], pr[25], pr[26], pr[27], pr[28]);
 #endif
     }
@@ -955,15 +976,19 @@ static int build_geometry_impl(rz_ctx* c, const rz_triangle* triangles, size_t n
     if (capNodes > ((size_t)1 << 30)) return fail(c, RZ_ERR_INVALID_ARG, "too many nodes");
     RZ_HIP(c, hipSetDevice(c->device));
     if (c->deviceOwnsTlas) { int rc = sync_host_from_device(c); if (rc != RZ_OK) return rc; }
-    int rc = ensure(c, c->dRawNodes, std::max<size_t>(capNodes, 1) * sizeof(rz_bvh_node));
+    // The build goes into FRESH buffers that replace the context's node / index arrays only when every mesh has been built:
+    // a call that fails half-way (HIP error, internal limit, out of host memory) leaves the context exactly as it was -- the
+    // arrays of an earlier rz_build_geometry, which devRoots / devNodes / geomOnDevice still describe, are never written to.
+    struct Fresh { DevBuf nodes, idx; ~Fresh() { nodes.release(); idx.release(); } } fresh;
+    int rc = ensure(c, fresh.nodes, std::max<size_t>(capNodes, 1) * sizeof(rz_bvh_node));
     if (rc != RZ_OK) return rc;
-    rc = ensure(c, c->dRawIdx, std::max<size_t>(capIdx, 1) * sizeof(int32_t));
+    rc = ensure(c, fresh.idx, std::max<size_t>(capIdx, 1) * sizeof(int32_t));
     if (rc != RZ_OK) return rc;
     if (maxN) { rc = ensure(c, c->dBuildWs, blas_build_workspace_bytes(maxN)); if (rc != RZ_OK) return rc; }
     std::map<int, rz_bvh_node> roots;
     size_t nodeOff = 0, idxOff = 0;
-    rz_bvh_node* dNodes = static_cast<rz_bvh_node*>(c->dRawNodes.p);
-    int32_t* dIdx = static_cast<int32_t*>(c->dRawIdx.p);
+    rz_bvh_node* dNodes = static_cast<rz_bvh_node*>(fresh.nodes.p);
+    int32_t* dIdx = static_cast<int32_t*>(fresh.idx.p);
     for (size_t i = 0; i < nMeshes; ++i) {
         rz_mesh_build& m = meshes[i];
         int nn = 1, depth = 1;
@@ -989,7 +1014,13 @@ static int build_geometry_impl(rz_ctx* c, const rz_triangle* triangles, size_t n
     // the three geometry bindings now are: the caller's triangles (host copy, uploaded by the re-layout as usual) and the
     // device-resident node / index arrays
     alloc_point(c);
-    c->host[RZ_BIND_TRIANGLES].assign(reinterpret_cast<const unsigned char*>(triangles), reinterpret_cast<const unsigned char*>(triangles) + nTris * sizeof(rz_triangle));
+    {   // (the last allocation that can fail: a copy first, then nothing below throws)
+        std::vector<unsigned char> tcopy(reinterpret_cast<const unsigned char*>(triangles), reinterpret_cast<const unsigned char*>(triangles) + nTris * sizeof(rz_triangle));
+        c->host[RZ_BIND_TRIANGLES].swap(tcopy);
+    }
+    RZ_HIP(c, hipStreamSynchronize(c->stream));        // nothing in flight reads the old arrays
+    std::swap(c->dRawNodes, fresh.nodes);               // (the old ones are released with `fresh`)
+    std::swap(c->dRawIdx, fresh.idx);
     c->host[RZ_BIND_BLAS_NODES].clear();
     c->host[RZ_BIND_BLAS_INDICES].clear();
     c->present[RZ_BIND_TRIANGLES] = c->present[RZ_BIND_BLAS_NODES] = c->present[RZ_BIND_BLAS_INDICES] = true;
@@ -1084,9 +1115,11 @@ static int set_frame_impl(rz_ctx* c, const rz_frame_params* p) {
 
 int rz_set_stream(rz_ctx* c, void* hip_stream) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
-    (void)hipStreamSynchronize(c->stream);
-    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->ownStream;
-    return RZ_OK;
+    return guarded(c, "rz_set_stream", [&]() -> int {
+        (void)hipStreamSynchronize(c->stream);
+        c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->ownStream;
+        return RZ_OK;
+    });
 }
 
 static int bind_accum_impl(rz_ctx* c, void* device_rgba, size_t bytes) {
@@ -1112,8 +1145,10 @@ int rz_render_counted(rz_ctx* c, rz_counters* out) {
 
 int rz_sync(rz_ctx* c) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
-    RZ_HIP(c, hipStreamSynchronize(c->stream));
-    return RZ_OK;
+    return guarded(c, "rz_sync", [&]() -> int {
+        RZ_HIP(c, hipStreamSynchronize(c->stream));
+        return RZ_OK;
+    });
 }
 
 void* rz_stream_handle(rz_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
@@ -1246,13 +1281,15 @@ static int present_impl(rz_ctx* c, const rz_present_params* pp, uint8_t* rgba8, 
 int rz_last_render_ms(rz_ctx* c, float* ms, int* launches) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
     if (!c->timed) return fail(c, RZ_ERR_NOT_READY, "nothing rendered yet");
-    const int slot = (c->ringHead + rz_ctx::kRing - 1) % rz_ctx::kRing;
-    RZ_HIP(c, hipEventSynchronize(c->evStop[slot]));
-    float t = 0.0f;
-    RZ_HIP(c, hipEventElapsedTime(&t, c->evStart[slot], c->evStop[slot]));
-    if (ms) *ms = t;
-    if (launches) *launches = c->lastLaunches;
-    return RZ_OK;
+    return guarded(c, "rz_last_render_ms", [&]() -> int {
+        const int slot = (c->ringHead + rz_ctx::kRing - 1) % rz_ctx::kRing;
+        RZ_HIP(c, hipEventSynchronize(c->evStop[slot]));
+        float t = 0.0f;
+        RZ_HIP(c, hipEventElapsedTime(&t, c->evStart[slot], c->evStop[slot]));
+        if (ms) *ms = t;
+        if (launches) *launches = c->lastLaunches;
+        return RZ_OK;
+    });
 }
 
 const char* rz_last_kernel_name(const rz_ctx* c) { return c ? c->lastKernel : ""; }
@@ -1260,14 +1297,16 @@ const char* rz_last_kernel_name(const rz_ctx* c) { return c ? c->lastKernel : ""
 int rz_render_history_ms(rz_ctx* c, float* ms, int cap) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
     if (cap < 0 || (cap > 0 && !ms)) return fail(c, RZ_ERR_INVALID_ARG, "bad history buffer");
-    const int n = std::min(c->ringCount, cap);
-    for (int i = 0; i < n; ++i) {     // oldest of the last n first
-        const int slot = (c->ringHead + 2 * rz_ctx::kRing - n + i) % rz_ctx::kRing;
-        RZ_HIP(c, hipEventSynchronize(c->evStop[slot]));
-        RZ_HIP(c, hipEventElapsedTime(&ms[i], c->evStart[slot], c->evStop[slot]));
-    }
-    c->ringCount = 0;
-    return n;
+    return guarded(c, "rz_render_history_ms", [&]() -> int {
+        const int n = std::min(c->ringCount, cap);
+        for (int i = 0; i < n; ++i) {     // oldest of the last n first
+            const int slot = (c->ringHead + 2 * rz_ctx::kRing - n + i) % rz_ctx::kRing;
+            RZ_HIP(c, hipEventSynchronize(c->evStop[slot]));
+            RZ_HIP(c, hipEventElapsedTime(&ms[i], c->evStart[slot], c->evStop[slot]));
+        }
+        c->ringCount = 0;
+        return n;
+    });
 }
 
 // ---- exported wrappers: no exception leaves the library (guarded(), above) ----

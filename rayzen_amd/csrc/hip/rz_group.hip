@@ -101,6 +101,9 @@ struct rz_group {
     size_t frameBytes = 0;
     int frameLocal = -1;                // local index of the member that holds `frame`
     int lastRoot = -1;
+    // HIP events on each member's stream around its share of the last rz_group_reduce (rz_group_last_reduce_ms)
+    std::vector<hipEvent_t> evBefore, evAfter;
+    bool reduceTimed = false;
     int width = 0, height = 0;
     bool haveFrame = false;
     std::string err;
@@ -133,6 +136,11 @@ void destroy_members(rz_group* g) {
     for (size_t i = 0; i < g->comm.size(); ++i)
         if (g->comm[i]) { (void)hipSetDevice(g->device[i]); (void)g_rccl.CommDestroy(g->comm[i]); }
     if (g->frame && g->frameLocal >= 0) { (void)hipSetDevice(g->device[g->frameLocal]); (void)hipFree(g->frame); }
+    for (size_t i = 0; i < g->evBefore.size(); ++i) {
+        (void)hipSetDevice(g->device[i]);
+        if (g->evBefore[i]) (void)hipEventDestroy(g->evBefore[i]);
+        if (g->evAfter[i]) (void)hipEventDestroy(g->evAfter[i]);
+    }
     for (rz_ctx* c : g->ctx) rz_destroy(c);
 }
 
@@ -298,6 +306,20 @@ int rz_group_reduce(rz_group* g, int root) {
         g->frameBytes = count * 4;
         g->frameLocal = rl;
     }
+    // events around each member's share (created on first use, on the member's device)
+    if (g->evBefore.size() != g->ctx.size()) {
+        g->evBefore.assign(g->ctx.size(), nullptr);
+        g->evAfter.assign(g->ctx.size(), nullptr);
+        for (size_t i = 0; i < g->ctx.size(); ++i) {
+            RZG_HIP(g, hipSetDevice(g->device[i]));
+            RZG_HIP(g, hipEventCreate(&g->evBefore[i]));
+            RZG_HIP(g, hipEventCreate(&g->evAfter[i]));
+        }
+    }
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        RZG_HIP(g, hipSetDevice(g->device[i]));
+        RZG_HIP(g, hipEventRecord(g->evBefore[i], static_cast<hipStream_t>(rz_stream_handle(g->ctx[i]))));
+    }
     // one collective per member, on the stream its render kernel was enqueued on; grouped so that one process
     // driving several devices cannot deadlock on launch order
     RZG_NCCL(g, g_rccl.GroupStart());
@@ -314,7 +336,29 @@ int rz_group_reduce(rz_group* g, int root) {
         }
     }
     RZG_NCCL(g, g_rccl.GroupEnd());
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        RZG_HIP(g, hipSetDevice(g->device[i]));
+        RZG_HIP(g, hipEventRecord(g->evAfter[i], static_cast<hipStream_t>(rz_stream_handle(g->ctx[i]))));
+    }
+    g->reduceTimed = true;
     g->lastRoot = root;
+    return RZ_OK;
+}
+
+int rz_group_last_reduce_ms(rz_group* g, float* root_ms, float* max_ms) {
+    if (!g) return gfail(nullptr, RZ_ERR_INVALID_ARG, "null group");
+    if (!g->reduceTimed) return gfail(&g->err, RZ_ERR_NOT_READY, "rz_group_reduce has not been called");
+    float worst = 0.0f, atRoot = -1.0f;
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        RZG_HIP(g, hipSetDevice(g->device[i]));
+        RZG_HIP(g, hipEventSynchronize(g->evAfter[i]));
+        float t = 0.0f;
+        RZG_HIP(g, hipEventElapsedTime(&t, g->evBefore[i], g->evAfter[i]));
+        worst = t > worst ? t : worst;
+        if (g->rank[i] == g->lastRoot) atRoot = t;
+    }
+    if (root_ms) *root_ms = atRoot;
+    if (max_ms) *max_ms = worst;
     return RZ_OK;
 }
 

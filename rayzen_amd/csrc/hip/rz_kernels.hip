@@ -185,7 +185,7 @@ __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
     a.light_fetches += b.light_fetches; a.samples += b.samples;
 #ifdef RZ_PROF
     for (int k = 0; k < 16; ++k) a.p[k] += b.p[k];
-    for (int k = 0; k < 12; ++k) a.t[k] += b.t[k];
+    for (int k = 0; k < 16; ++k) a.t[k] += b.t[k];
     for (int r = 0; r < 8; ++r) { a.rt[r] += b.rt[r]; for (int k = 0; k < 10; ++k) a.rp[r][k] += b.rp[r][k]; }
 #endif
 }
@@ -202,6 +202,14 @@ __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
 #endif
 #ifndef RZ_GROUPS_PER_CLAIM
 #define RZ_GROUPS_PER_CLAIM 8
+#endif
+#ifdef RZ_NO_SPREAD          // (A/B aid: compile trace_spread out altogether)
+#define RZ_SPREAD_ON(K) false
+#else
+#define RZ_SPREAD_ON(K) ((K).spreadTrace != 0)
+#endif
+#ifndef RZ_CLAIM_RUN_SMALL_SPP
+#define RZ_CLAIM_RUN_SMALL_SPP 1
 #endif
 #ifndef RZ_COMPACT_DEFAULT
 #define RZ_COMPACT_DEFAULT 1     // compaction of late bounces across a claim (render_claim_compact); RZ_COMPACT=0/1 overrides at run time
@@ -290,10 +298,12 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime();
                 unsigned long long t2 = t1;
 #endif
+                // the wave's rays have spread once every running lane is on its third or a later segment (rz_trace.h: trace_spread)
+                const bool spread = RZ_SPREAD_ON(K) && rz_ballot(P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= 2)) == 0ull;
                 if (P.mode != MODE_DONE) {
                     RZ_SITE(c, 6);
                     HitRec h;
-                    const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, c);
+                    const bool found = spread ? trace_spread<COUNT, OVF>(K, P.o, P.d, h, bstk, c) : trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, c);
 #ifdef RZ_PROF
                     t2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -389,12 +399,15 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
 #ifdef RZ_PROF
                     RZ_SITE(c, 6);
                     const unsigned long long tq0_ = __builtin_amdgcn_s_memtime();
-                    const bool found = trace_closest<false, OVF>(K, P.o, P.d, h, bstk, c);
+                    const bool found = (RZ_SPREAD_ON(K) && rz_ballot(!(P.mode == MODE_SEGMENT && P.bounce >= 2)) == 0ull)
+                                           ? trace_spread<false, OVF>(K, P.o, P.d, h, bstk, c) : trace_closest<false, OVF>(K, P.o, P.d, h, bstk, c);
                     c.rt[c.rnd & 7] += __builtin_amdgcn_s_memtime() - tq0_;
                     if (c.rnd < 7) ++c.rnd;
                     advance<false, true>(K, P, found, h, c);
 #else
-                    const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, COUNT ? att : c);
+                    // (the lanes still in this loop have spread once they all are on their third or a later segment: rz_trace.h, trace_spread)
+                    const bool found = (RZ_SPREAD_ON(K) && rz_ballot(!(P.mode == MODE_SEGMENT && P.bounce >= 2)) == 0ull)
+                                           ? trace_spread<COUNT, OVF>(K, P.o, P.d, h, bstk, COUNT ? att : c) : trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, COUNT ? att : c);
                     advance<COUNT, true>(K, P, found, h, COUNT ? att : c);
 #endif
                 }
@@ -495,6 +508,26 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
 
 
 
+// Which pixel groups make up claim ci of a persistent launch.  A claim is `perClaim` groups: RUNS of 2^runShift consecutive
+// groups, one run from each of perClaim >> runShift equal bands of the launch's groups (band j = runs j * nClaims ...).  With
+// one run (runShift = log2 perClaim) a claim is perClaim consecutive groups -- a row of an 8x8 tile at 64 spp, the shape
+// round 2 settled on there.  With several, every claim holds a sample of the whole frame, top to bottom, so claims cost
+// about the same: a launch cannot end before its last claim does, and a claim that lies wholly inside a mesh takes many
+// times the average (C4, 16 spp, 4 pixels per group: 4 / 8 / 16 consecutive groups per claim ran the frame in 10.8 / 12.9 /
+// 18.2 ms against 9.4 without claims -- the tail grew with the claim).
+struct ClaimMap {
+    unsigned nGroups, perClaim, nClaims, runShift;
+    __device__ __forceinline__ int group(unsigned ci, int g) const {
+        const unsigned j = (unsigned)g >> runShift, w = (unsigned)g & ((1u << runShift) - 1u);
+        return (int)(((j * nClaims + ci) << runShift) + w);
+    }
+    __device__ __forceinline__ int units_of(unsigned ci) const {       // the claim's groups that exist (a prefix: group() grows with g)
+        int n = 0;
+        for (unsigned g = 0; g < perClaim; ++g) n += (unsigned)group(ci, (int)g) < nGroups ? 1 : 0;
+        return n;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // render_claim_compact: the opaque spp >= 64 persistent path with RAY COMPACTION across the pixels of a claim
 // (north_star: "wavefront ballot / prefix-sum ray compaction for divergent bounces").
@@ -510,7 +543,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
 // Scratch is private to the resident wave and is only ever read by the wave that wrote it (L1/L2 hits); the
 // __syncthreads() of the one-wave workgroup order its stores before its loads.
 template <bool COUNT, bool OVF, int UNITS>
-__device__ __forceinline__ void render_claim_compact(const KParams& K, const unsigned base, const unsigned end, unsigned char* lds_raw) {
+__device__ __forceinline__ void render_claim_compact(const KParams& K, const ClaimMap M, const unsigned ci, unsigned char* lds_raw) {
     const int lane = threadIdx.x & 63;
     const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + lane,
                                OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + lane : nullptr, K.blasStackCap};
@@ -519,40 +552,66 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
     constexpr int PS = UNITS * 64;                    // pool stride (slots per field)
     const int spp = K.spp;
     const int nBatches = (spp + 63) / 64;
-    const int nPix = (int)(end - base);
-    const int nUnits = nPix * nBatches;               // <= UNITS by the launch plan
+    // a unit is one wave's worth of samples: a 64-sample batch of one pixel (spp >= 64), or all spp samples of each of the
+    // ppw = 64 / spp pixels of a group (spp < 64: lane = pixel-in-group * spp + sample, the pixels a compact block of the tile)
+    const int ppw = spp >= 64 ? 1 : 64 / spp;
+    const int nGroups = M.units_of(ci);
+    const int nPix = nGroups * ppw;                   // pixels of the claim: slots base * ppw ... + nPix - 1
+    const int nUnits = nGroups * nBatches;            // <= UNITS by the launch plan
+    const int pixInUnit = spp >= 64 ? 0 : lane / spp; // (a lane with pixInUnit >= ppw is idle: spp need not divide 64)
+    const int sampInUnit = spp >= 64 ? lane : lane - pixInUnit * spp;
     int nPool = 0, unit = 0, poolBase = 0, poolWrite = 0;     // wave-uniform
     int tileCached = -1, tileX = 0, tileY = 0;                // wave-uniform: the tile of the current unit
     Tally c = {};
-    Path P;
-    P.mode = MODE_DONE;
     unsigned guard = 0;
     bool cont;
     do {                                                        // (one exit, at the end: see blas_walk; the bound is a backstop: units + pool rounds of at most maxBounces generations)
         const bool phase2 = unit >= nUnits;
+        Path P;         // (per round: nothing of a path lives across rounds -- declared outside, all its fields stayed allocated across pool_trace)
 #ifdef RZ_PROF
         const unsigned long long tph0_ = __builtin_amdgcn_s_memtime();
 #endif
         int backUnit = 0, backLane = lane;
         bool poolLane = false;
+        int qTri = -1, qInst = 0;               // phase 2: the winner of this lane's query (pool_trace)
+        if (phase2 && poolBase == 0) {
+            // a generation of the pool starts: ALL its closest-hit queries are traced together, the lanes refilling from the
+            // list of pending BLAS walks (rz_trace.h: pool_trace); the rounds below only shade the results, 64 paths at a time
+#ifdef RZ_PROF
+            const unsigned long long tpt0_ = __builtin_amdgcn_s_memtime();
+#endif
+            pool_trace<COUNT, OVF, PS>(K, pool, nPool, bstk, c);
+#ifdef RZ_PROF
+            c.t[12] += __builtin_amdgcn_s_memtime() - tpt0_;
+#endif
+        }
         P.mode = MODE_DONE;
         P.addLight = mk3(0.0f, 0.0f, 0.0f);
         P.addSky = mk3(0.0f, 0.0f, 0.0f);
         P.usedIor = 0;
         P.ior = 1.0f;
         if (!phase2) {
-            const int p = nBatches == 1 ? unit : unit / nBatches, b = unit - p * nBatches;
-            const int slot = (int)base + p;
+            const int g = nBatches == 1 ? unit : unit / nBatches, b = unit - g * nBatches;
+            const int slot = M.group(ci, g) * ppw + pixInUnit;
             const int localTile = slot >> 6, l = slot & 63;
-            if (localTile != tileCached) {      // (wave-uniform; a claim lies within one tile unless its size does not divide 64)
-                tileCached = localTile;
+            int px, py;
+            if (spp >= 64 || (64 % ppw) == 0) {
+                // (wave-uniform: the group's pixels lie in one tile; a claim lies within one tile unless its size does not divide 64)
+                const int ut = __builtin_amdgcn_readfirstlane(localTile);
+                if (ut != tileCached) {
+                    tileCached = ut;
+                    const int tile = ut * K.tileNRanks + K.tileRank;
+                    tileY = tile / K.tilesX;        // the integer division costs ~40 instructions: once per claim, not per unit
+                    tileX = tile - tileY * K.tilesX;
+                }
+                px = tileX * RZ_TILE_W + slot_x(l, spp < 64); py = tileY * RZ_TILE_H + slot_y(l, spp < 64);
+            } else {                                // 64 / spp pixels per group does not divide the tile's 64: a group can straddle two tiles
                 const int tile = localTile * K.tileNRanks + K.tileRank;
-                tileY = tile / K.tilesX;        // the integer division costs ~40 instructions: once per claim, not per unit
-                tileX = tile - tileY * K.tilesX;
+                const int ty = tile / K.tilesX, tx = tile - ty * K.tilesX;
+                px = tx * RZ_TILE_W + slot_x(l, true); py = ty * RZ_TILE_H + slot_y(l, true);
             }
-            const int px = tileX * RZ_TILE_W + slot_x(l, false), py = tileY * RZ_TILE_H + slot_y(l, false);
-            const int s = b * 64 + lane;
-            if (slot < K.nSlots && px < K.width && py < K.height && s < spp) {
+            const int s = b * 64 + sampInUnit;
+            if (pixInUnit < ppw && slot < K.nSlots && px < K.width && py < K.height && s < spp) {
                 const float fragx = (float)px + 0.5f, fragy = (float)py + 0.5f;
                 P.uv.x = fragx / (float)K.width;
                 P.uv.y = fragy / (float)K.height;
@@ -577,6 +636,8 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
                 backLane = (int)(bb & 63u);
                 P.color = mk3(0.0f, 0.0f, 0.0f);
                 P.mode = MODE_SEGMENT;
+                qTri = (int)pool[poolf::QTRI * PS + sl];
+                qInst = (int)pool[poolf::QINST * PS + sl];
             }
         }
         // ONE trace / advance loop serves both phases.  Phase 1: a unit's paths run until they finish or stand in front
@@ -599,7 +660,23 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
                 RZ_SITE(c, 6);
                 const unsigned long long tq0_ = __builtin_amdgcn_s_memtime();
 #endif
-                const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, c);
+                bool found;
+                if (!phase2) {
+                    found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, c);
+                } else {
+                    // the query was traced with the rest of its generation: its winner's point, normal and material, as at the end
+                    // of trace_closest (FS:411-412, 489-491)
+                    found = qTri >= 0;
+                    if (found) {
+                        const int sl = poolBase + lane;
+                        const float4 nm = *reinterpret_cast<const float4*>(K.triN + qTri);
+                        h.t = __uint_as_float(pool[poolf::QT * PS + sl]);
+                        h.p = mk3(__uint_as_float(pool[poolf::QPX * PS + sl]), __uint_as_float(pool[poolf::QPY * PS + sl]), __uint_as_float(pool[poolf::QPZ * PS + sl]));
+                        h.n = normalize(x34_normal(K.instances[qInst].inv, mk3(nm.x, nm.y, nm.z)));
+                        h.mat = __float_as_int(nm.w);
+                        h.inst = qInst;
+                    }
+                }
 #ifdef RZ_PROF
                 c.rt[c.rnd & 7] += __builtin_amdgcn_s_memtime() - tq0_;
 #endif
@@ -661,14 +738,18 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
         }
     } while (cont && ++guard < (1u << 20));
     __syncthreads();
-    // ---- the claim's ordered sums: lane 3p + ch replays pixel p's additions of channel ch in sample order
-    {
-        const int p = lane / 3, ch = lane - 3 * p;
+    // ---- the claim's ordered sums: 21 pixels per pass, lane 3 q + ch replays the additions of channel ch of the pass's q-th
+    // pixel in sample order (spp >= 64: a claim has at most 16 pixels -- one pass, 24 or 48 lanes busy; spp < 64: up to 64
+    // pixels per unit, each summing its spp entries of one unit's addends)
+    for (int p0 = 0; p0 < nPix; p0 += 21) {
+        const int q = lane / 3, ch = lane - 3 * q;
+        const int p = p0 + q;
         bool inside = false;
         size_t pix = 0;
         float chan = 0.0f, alpha = 0.0f;
-        if (p < nPix) {
-            const int slot = (int)base + p;
+        if (q < 21 && p < nPix) {
+            const int gq = p / ppw;
+            const int slot = M.group(ci, gq) * ppw + (p - gq * ppw);
             const int localTile = slot >> 6, l = slot & 63;
             int tx = tileX, ty = tileY;         // the last unit's tile: the right one unless the claim straddles two tiles
             if (localTile != tileCached) {
@@ -688,23 +769,24 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
             }
         }
         if (inside) {
+            const int g = p / ppw, lane0 = (p - g * ppw) * spp;      // spp < 64: the pixel's unit and its first lane there
             for (int b = 0; b < nBatches; ++b) {
-                const float* Lf = addBase + (size_t)(p * nBatches + b) * 384 + 64 * ch;
+                const float* Lf = addBase + (size_t)(spp >= 64 ? p * nBatches + b : g) * 384 + 64 * ch + (spp >= 64 ? 0 : lane0);
                 const float* Sf = Lf + 192;
-                const int n = min(64, spp - b * 64);
+                const int n = spp >= 64 ? min(64, spp - b * 64) : spp;
                 int k = 0;
                 for (; k + 8 <= n; k += 8) {
-                    float l[8], q[8];
+                    float l[8], q8[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { l[u] = Lf[k + u]; q[u] = Sf[k + u]; }
+                    for (int u = 0; u < 8; ++u) { l[u] = Lf[k + u]; q8[u] = Sf[k + u]; }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { chan = chan + l[u]; chan = chan + q[u]; }   // FS:717, FS:709
+                    for (int u = 0; u < 8; ++u) { chan = chan + l[u]; chan = chan + q8[u]; }   // FS:717, FS:709
                 }
                 for (; k < n; ++k) { chan = chan + Lf[k]; chan = chan + Sf[k]; }
             }
         }
-        const int l0 = 3 * p < 64 ? 3 * p : 0;
-        const float cx = __shfl(chan, l0), cy = __shfl(chan, (l0 + 1) & 63), cz = __shfl(chan, (l0 + 2) & 63);
+        const int l0 = q < 21 ? 3 * q : 0;
+        const float cx = __shfl(chan, l0), cy = __shfl(chan, l0 + 1), cz = __shfl(chan, l0 + 2);
         if (inside && ch == 0) {
             K.accum[pix] = make_float4(cx, cy, cz, alpha + (float)spp);
             K.ior[pix] = 1.0f;
@@ -726,7 +808,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
 #ifdef RZ_PROF
         unsigned long long* pr = reinterpret_cast<unsigned long long*>(K.counters + 1);
         for (int k = 0; k < 16; ++k) if (c.p[k]) atomicAdd(&pr[k], (unsigned long long)c.p[k]);
-        if (lane == 0) for (int k = 0; k < 12; ++k) atomicAdd(&pr[19 + k], c.t[k]);
+        if (lane == 0) { for (int k = 0; k < 12; ++k) atomicAdd(&pr[19 + k], c.t[k]); for (int k = 12; k < 16; ++k) atomicAdd(&pr[108 + k], c.t[k]); }
         rz_prof_rounds(c, pr);
 #endif
     }
@@ -734,7 +816,8 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const uns
 }
 
 template <bool COUNT, bool GLASS, bool OVF, int COMPACT>      // COMPACT: 0, or the units of a compacting claim (8 / 16)
-__global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES_MIN_WAVES) void rz_render_samples(const KParams K, const unsigned nGroups, const unsigned perClaim) {
+__global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES_MIN_WAVES) void rz_render_samples(const KParams K, const unsigned nGroups, const unsigned perClaim,
+                                                                                                                  const unsigned nClaims, const unsigned runShift) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 #ifdef RZ_PROF
     const unsigned long long wl_t0 = __builtin_amdgcn_s_memrealtime();
@@ -744,19 +827,20 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
         render_samples_group<COUNT, GLASS, OVF>(K, blockIdx.x, lds_raw);
         return;
     }
+    const ClaimMap M{nGroups, perClaim, nClaims, runShift};
     for (;;) {
-        unsigned base = 0;
-        if ((threadIdx.x & 63) == 0) base = atomicAdd(K.groupCounter, perClaim);
-        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-        if (base >= nGroups) break;             // every wave of the grid reaches this: the counter only grows
+        unsigned ci = 0;
+        if ((threadIdx.x & 63) == 0) ci = atomicAdd(K.groupCounter, 1u);
+        ci = (unsigned)__builtin_amdgcn_readfirstlane((int)ci);
+        if (ci >= nClaims) break;               // every wave of the grid reaches this: the counter only grows
 #ifdef RZ_PROF
         ++wl_claims;
 #endif
-        const unsigned end = base + perClaim < nGroups ? base + perClaim : nGroups;
         if constexpr (COMPACT != 0 && !GLASS) {
-            render_claim_compact<COUNT, OVF, COMPACT>(K, base, end, lds_raw);
+            render_claim_compact<COUNT, OVF, COMPACT>(K, M, ci, lds_raw);
         } else {
-            for (unsigned wb = base; wb < end; ++wb) render_samples_group<COUNT, GLASS, OVF>(K, wb, lds_raw);
+            const int n = M.units_of(ci);
+            for (int g = 0; g < n; ++g) render_samples_group<COUNT, GLASS, OVF>(K, (unsigned)M.group(ci, g), lds_raw);
         }
     }
 #ifdef RZ_PROF
@@ -856,7 +940,14 @@ SamplesPlan plan_render_samples(int spp, int nSlots, bool glass) {
     //  * 16 units from 4 M units on (C3: 256 spp at 1080p; C5: 128 spp at 4K): more pixels per claim, so more paths to compact
     //     and more lanes in the ordered sums, and the tail no longer shows: C3 44.7 -> 43.0 ms, C5 118.2 -> 115.6.
     const int claimUnits = units >= (4ll << 20) ? RZ_CLAIM_UNITS_LARGE : (units >= (3ll << 18) ? RZ_GROUPS_PER_CLAIM : std::max(1, RZ_GROUPS_PER_CLAIM / 2));
-    p.perClaim = (spp >= 64 && p.groups >= (long long)nCU * RZ_PERSIST_WAVES_PER_CU * 16) ? std::max(1, claimUnits / nBatches) : 0;
+    // Launches of several pixels per wave (spp < 64) take the persistent, compacting grid too (round 3): their late bounces
+    // are where their time goes -- C4, 16 spp: rounds 4 and 5 of a path (bounces 2 and 3) ran 7 and 3 lanes wide and took 39 %
+    // of the traversal's wave cycles (profiles/r03_c4_before/) -- and only a claim of several units has enough parked paths to
+    // fill waves with.  RZ_SMALL_SPP_CLAIMS=0 restores one workgroup per group (A/B aid).
+    bool smallSppClaims = true;
+    if (const char* e = std::getenv("RZ_SMALL_SPP_CLAIMS")) smallSppClaims = std::atoi(e) != 0;
+    const bool persistent = (spp >= 64 || smallSppClaims) && p.groups >= (long long)nCU * RZ_PERSIST_WAVES_PER_CU * 16;
+    p.perClaim = persistent ? std::max(1, claimUnits / nBatches) : 0;
     if (const char* e = std::getenv("RZ_GROUPS_PER_CLAIM")) p.perClaim = std::max(0, std::atoi(e));      // tuning aid
     // ray compaction across the units of a claim (render_claim_compact, instantiated for 8 and for 16 units): opaque scenes,
     // persistent launches, up to 16 batches per pixel (a unit is ONE pixel's batch of 64 samples)
@@ -865,7 +956,8 @@ SamplesPlan plan_render_samples(int spp, int nSlots, bool glass) {
     // (measured: C2, 64 spp, 14.29 -> 13.28 ms; 128 spp C5 144.2 -> 143.0.  Several batches per pixel -- a claim is then a few
     //  pixels' batches: at mid-round the gain was gone at 256 spp, on the final code it is back: C3 47.3 -> 44.7 ms, one rank's
     //  share of a 4- / 8-GPU weak-scaling frame (256 / 512 spp) 11.88 -> 11.25 / 11.85 -> 11.70 ms)
-    p.compact = compact && !glass && p.perClaim > 0 && nBatches <= RZ_CLAIM_UNITS_LARGE && spp >= 64;
+    p.compact = compact && !glass && p.perClaim > 0 && nBatches <= RZ_CLAIM_UNITS_LARGE;
+    if (spp < 64 && !p.compact) p.perClaim = 0;          // (the plain persistent loop never paid for several pixels per wave: C4 9.4 -> 10.8 ... 19.9 ms)
     p.claimUnits = 0;
     if (p.compact) {
         p.claimUnits = (p.perClaim * nBatches > RZ_CLAIM_UNITS_SMALL) ? RZ_CLAIM_UNITS_LARGE : RZ_CLAIM_UNITS_SMALL;
@@ -873,6 +965,16 @@ SamplesPlan plan_render_samples(int spp, int nSlots, bool glass) {
     }
     const long long claims = p.perClaim ? (p.groups + p.perClaim - 1) / p.perClaim : p.groups;
     p.grid = p.perClaim ? std::min<long long>(claims, (long long)nCU * RZ_PERSIST_WAVES_PER_CU) : p.groups;
+    p.nClaims = p.perClaim ? claims : 0;
+    // the shape of a claim (ClaimMap): one run of consecutive groups at 64 spp and more (a tile row; its parked paths are
+    // neighbours), runs of RZ_CLAIM_RUN_SMALL_SPP groups from as many bands of the frame as it takes below (a claim of
+    // consecutive 4-pixel groups inside a mesh costs many times the average claim, and the launch waits for the last one)
+    int run = spp >= 64 ? p.perClaim : RZ_CLAIM_RUN_SMALL_SPP;
+    if (const char* e = std::getenv("RZ_CLAIM_RUN")) run = std::max(1, std::atoi(e));                        // tuning aid
+    if (run > p.perClaim) run = p.perClaim;
+    if (run <= 0 || (run & (run - 1)) != 0 || p.perClaim % run != 0) run = 1;      // runs are a power of two that divides the claim; anything else: single groups
+    p.runShift = 0;
+    while ((1 << (p.runShift + 1)) <= run) ++p.runShift;
     return p;
 }
 size_t samples_lds_extra(bool glass, bool compact) {      // LDS per wave besides the two stacks
@@ -890,7 +992,7 @@ void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream
     const unsigned nGroups = (unsigned)blocks;
     if (perClaim && hipMemsetAsync(K.groupCounter, 0, sizeof(unsigned), stream) != hipSuccess) return;
     const bool ovf = K.blasOvfCap > 0;           // only set for persistent launches (rz_context.hip: render_samples)
-#define RZ_LAUNCH_SAMPLES(C, G, O, M) hipLaunchKernelGGL((rz_render_samples<C, G, O, M>), g, b, lds, stream, K, nGroups, (unsigned)perClaim)
+#define RZ_LAUNCH_SAMPLES(C, G, O, M) hipLaunchKernelGGL((rz_render_samples<C, G, O, M>), g, b, lds, stream, K, nGroups, (unsigned)perClaim, (unsigned)plan.nClaims, (unsigned)plan.runShift)
     if (glass) {
         if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, true, true, 0); else RZ_LAUNCH_SAMPLES(true, true, false, 0); }
         else { if (ovf) RZ_LAUNCH_SAMPLES(false, true, true, 0); else RZ_LAUNCH_SAMPLES(false, true, false, 0); }

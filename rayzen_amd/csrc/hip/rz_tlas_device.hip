@@ -3,7 +3,7 @@
 // Per frame RayZen re-reads every object's transform, inverts it, recomputes the world AABB of each BLAS root
 // (main.cpp:1168-1191), rebuilds the TLAS on the CPU (BVH.cpp:178-240) and re-uploads everything.  Here the frontend
 // hands over only the transforms (64 B per instance); one small kernel does the rest where the data lives:
-//   phase 1, one lane per instance: inverse (the host library's formula, rz_linalg.h, operation for operation),
+//   phase 1, one lane per instance: inverse (glm::inverse's published sequence, as rz_linalg.h, operation for operation),
 //            DevInstance 3x4 blocks, reference-layout BVHInstance, world AABB from the 8 corners;
 //   phase 2, 16 waves, level by level: the TLAS build exactly as BVH.cpp:178-240 (midpoint split on the longest axis,
 //            swap partition, count/2 fallback, one instance per leaf, left subtree numbered first).  The reference walks
@@ -36,30 +36,34 @@ namespace rz {
 __device__ inline float gmin(float a, float b) { return (b < a) ? b : a; }   // glm::min
 __device__ inline float gmax(float a, float b) { return (a < b) ? b : a; }   // glm::max
 
-// rz_linalg.h inverse(): same expressions, same order
+// glm::inverse(mat4), GLM 0.9.9.8's compute_inverse<4, 4> (the algorithm RayZen's main.cpp:1151 runs per object per frame;
+// rz_linalg.h and the oracle restate the same published sequence): 2x2 sub-determinants of rows 1..3, cofactor columns
+// (Vec_a * Fac_i - Vec_b * Fac_j) + Vec_c * Fac_l with alternating signs, determinant from the cofactors' first row
+// summed pairwise, every cofactor times its reciprocal.  One lane inverts one instance's matrix; -ffp-contract=off keeps
+// each product and sum a separate rounding, as on the host.
 __device__ void inverse4(const float* m, float* r) {
-    float s0 = m[0] * m[5] - m[1] * m[4], s1 = m[0] * m[6] - m[2] * m[4], s2 = m[0] * m[7] - m[3] * m[4];
-    float s3 = m[1] * m[6] - m[2] * m[5], s4 = m[1] * m[7] - m[3] * m[5], s5 = m[2] * m[7] - m[3] * m[6];
-    float c5 = m[10] * m[15] - m[11] * m[14], c4 = m[9] * m[15] - m[11] * m[13], c3 = m[9] * m[14] - m[10] * m[13];
-    float c2 = m[8] * m[15] - m[11] * m[12], c1 = m[8] * m[14] - m[10] * m[12], c0 = m[8] * m[13] - m[9] * m[12];
-    float det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
-    float id = 1.0f / det;
-    r[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * id;
-    r[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * id;
-    r[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * id;
-    r[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * id;
-    r[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * id;
-    r[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * id;
-    r[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * id;
-    r[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * id;
-    r[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * id;
-    r[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * id;
-    r[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * id;
-    r[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * id;
-    r[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * id;
-    r[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * id;
-    r[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * id;
-    r[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * id;
+    // GLM's eighteen coefficients are the 2x2 determinants of two ROWS (a < b) taken from two of the columns 1, 2, 3;
+    // Fac_f holds the three of one row pair -- (2,3) (1,3) (1,2) (0,3) (0,2) (0,1) for f = 0..5 -- its first one twice
+    const int ra[6] = {2, 1, 1, 0, 0, 0}, rb[6] = {3, 3, 2, 3, 2, 1};
+    float fac[6][3];
+    for (int f = 0; f < 6; ++f) {
+        const int a = ra[f], b = rb[f];
+        fac[f][0] = m[8 + a] * m[12 + b] - m[12 + a] * m[8 + b];      // columns 2, 3
+        fac[f][1] = m[4 + a] * m[12 + b] - m[12 + a] * m[4 + b];      // columns 1, 3
+        fac[f][2] = m[4 + a] * m[8 + b] - m[8 + a] * m[4 + b];        // columns 1, 2
+    }
+    const int va[4] = {1, 0, 0, 0}, vb[4] = {2, 2, 1, 1}, vc[4] = {3, 3, 3, 2};
+    const int fa[4] = {0, 0, 1, 2}, fb[4] = {1, 3, 3, 4}, fc[4] = {2, 4, 5, 5};
+    for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < 4; ++j) {
+            const int col = j == 0 ? 4 : 0;             // Vec_x[j] = m[1][x] for j = 0, m[0][x] otherwise
+            const int fj = j == 0 ? 0 : j - 1;          // Fac_x = (c, c, c', c'')
+            const float inv = (m[col + va[k]] * fac[fa[k]][fj] - m[col + vb[k]] * fac[fb[k]][fj]) + m[col + vc[k]] * fac[fc[k]][fj];
+            r[4 * k + j] = ((k + j) & 1) ? inv * -1.0f : inv * 1.0f;
+        }
+    const float det = (m[0] * r[0] + m[1] * r[4]) + (m[2] * r[8] + m[3] * r[12]);
+    const float id = 1.0f / det;
+    for (int k = 0; k < 16; ++k) r[k] = r[k] * id;
 }
 
 __global__ __launch_bounds__(1024) void rz_tlas_refit(const TlasWork W) {
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(1024) void rz_tlas_refit(const TlasWork W) {
             const float x = (c & 4) ? D.rootMax[0] : D.rootMin[0], y = (c & 2) ? D.rootMax[1] : D.rootMin[1],
                         z = (c & 1) ? D.rootMax[2] : D.rootMin[2];
             for (int r = 0; r < 3; ++r) {
-                const float t = m[r] * x + m[4 + r] * y + m[8 + r] * z + m[12 + r] * 1.0f;
+                const float t = (m[r] * x + m[4 + r] * y) + (m[8 + r] * z + m[12 + r] * 1.0f);     // glm mat4 * vec4: pairwise
                 mn[r] = gmin(mn[r], t);
                 mx[r] = gmax(mx[r], t);
             }

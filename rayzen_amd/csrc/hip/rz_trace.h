@@ -45,7 +45,7 @@ struct Tally {          // per-thread counts of the REFERENCE algorithm's memory
     int rnd;                    // which closest-hit query of its path this lane is in (0 primary, 1-2 shadow, 3.. bounces), capped at 7
     unsigned rp[8][10];         // per query round: wave-execs / lanes of [0,1] descend steps [2,3] triangle tests [4,5] instance entries [6,7] uniform-pair steps [8,9] queries
     unsigned long long rt[8];   // per query round: wave cycles inside trace_closest (lane 0's clock)
-    unsigned long long t[12];   // ([4] / [9]: phase 1 / pool rounds of a compacting claim, [10] pool rounds, [11] paths in them)   wave cycles (s_memtime): [0] descend loops, [1] leaf phases, [2] whole BLAS walks; rz_path.h advance(): [3] sky, [4] hit bookkeeping, [5] start_light, [6] shade_light, [7] scatter, [8] of it the hemisphere direction, [9] shadow-step bookkeeping
+    unsigned long long t[16];   // ([4] / [9]: phase 1 / pool rounds of a compacting claim, [10] pool rounds, [11] paths in them)   wave cycles (s_memtime): [0] descend loops, [1] leaf phases, [2] whole BLAS walks; rz_path.h advance(): [3] sky, [4] hit bookkeeping, [5] start_light, [6] shade_light, [7] scatter, [8] of it the hemisphere direction, [9] shadow-step bookkeeping
 #endif
 };
 #ifdef RZ_PROF
@@ -285,9 +285,12 @@ __device__ __forceinline__ bool pop_entry(const BlasStackT<OVF>& S, int& sp, flo
 // bstk: this lane's stack (LDS window + optional overflow).
 // Returns the winning triangle (absolute DevTri index) or -1; tLoc = its t.
 // OCT: -1 generic, 0..7 the wave's common direction octant (slab_finish).
-template <bool COUNT, bool OVF, int OCT>
+// MI ("many instances"): the lanes of the wave walk DIFFERENT instances at the same time -- `pairs` / `tris` are then the
+// scene's arrays, the lane's instance contributes its bases pbase / tbase, and a node number is only meaningful together
+// with its base.  Such waves hold incoherent rays (the late bounces), so the wave-uniform scalar fetch is not even tried.
+template <bool COUNT, bool OVF, int OCT, bool MI>
 __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, const DevTri* __restrict__ tris, v3 lo, v3 ld, v3 inv,
-                                         bool go, int cur, float& tLocOut, const BlasStackT<OVF>& bstk, Tally& c) {
+                                         bool go, int cur, int pbase, int tbase, float& tLocOut, const BlasStackT<OVF>& bstk, Tally& c) {
     float tLoc = 1e30f;
     int best = -1;
     int sp = 0;
@@ -324,7 +327,7 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
         while (more) {
             if (in_mask(actMask)) {
                 RZ_SITE(c, 3);
-                const DevPair* pp = pairs + cur;
+                const DevPair* pp = pairs + (MI ? pbase + cur : cur);
                 if (COUNT) c.blas_nodes += 2;        // the shader pushes, and later pops, both children
                 // The shader pushes left, then right, and pops right at once (FS:449-450, 428-430).
                 //  * right hit and not culled: continue into it; a hit left child waits on the stack with its entry distance;
@@ -345,8 +348,8 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
 #if RZ_SCALAR_UNIFORM
                 // (`pairs` is wave-uniform -- it comes from the instance record, a scalar fetch -- so comparing the 32-bit
                 //  node numbers does what comparing the 64-bit addresses did, and the address is computed on the scalar unit)
-                const int ucur = __builtin_amdgcn_readfirstlane(cur);
-                if (rz_ballot(cur != ucur) == 0ull) {     // every active lane wants the same pair: one scalar fetch,
+                const int ucur = MI ? 0 : __builtin_amdgcn_readfirstlane(cur);
+                if (!MI && rz_ballot(cur != ucur) == 0ull) {     // every active lane wants the same pair: one scalar fetch,
                     RZ_SITE(c, 7);                        // box values consumed straight from SGPRs
                     const f32x16 q = sload16_off(pairs, (unsigned)ucur << 6);     // (a BLAS's pairs span < 4 GiB: rz_context.hip, finalize)
                     const f32x2 lx = {q[0], q[1]}, ly = {q[2], q[3]}, lz = {q[4], q[5]};
@@ -384,7 +387,7 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
             // finished lane); a wave-uniform loop over the triangle slot, lanes with fewer triangles sit out
             const bool leaf = cur < 0;
             const int v = ~cur;
-            const int first = v >> 4, count = leaf ? (v & 15) : 0;
+            const int first = (v >> 4) + (MI ? tbase : 0), count = leaf ? (v & 15) : 0;
             if (COUNT) c.triangles += (unsigned)count;
             if (leaf) RZ_SITE(c, 1);
             int i = 0;
@@ -423,6 +426,7 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
 #ifndef RZ_OCTANT_SLAB
 #define RZ_OCTANT_SLAB 1
 #endif
+// The lanes of the wave enter ONE instance, `I` (wave-uniform: its record comes through the scalar cache).
 template <bool COUNT, bool OVF>
 __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance* __restrict__ I, v3 lo, v3 ld,
                                              float& tLocOut, const BlasStackT<OVF>& bstk, Tally& c) {
@@ -454,22 +458,37 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
             if (rz_ballot(go && (!fin || oct != first)) == 0ull) uoct = first;
         }
         switch (uoct) {
-            case 0: best = blas_walk<COUNT, OVF, 0>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-            case 1: best = blas_walk<COUNT, OVF, 1>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-            case 2: best = blas_walk<COUNT, OVF, 2>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-            case 3: best = blas_walk<COUNT, OVF, 3>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-            case 4: best = blas_walk<COUNT, OVF, 4>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-            case 5: best = blas_walk<COUNT, OVF, 5>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-            case 6: best = blas_walk<COUNT, OVF, 6>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-            case 7: best = blas_walk<COUNT, OVF, 7>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-            default: best = blas_walk<COUNT, OVF, -1>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
+            case 0: best = blas_walk<COUNT, OVF, 0, false>(pairs, tris, lo, ld, inv, go, cur, 0, 0, tLocOut, bstk, c); break;
+            case 1: best = blas_walk<COUNT, OVF, 1, false>(pairs, tris, lo, ld, inv, go, cur, 0, 0, tLocOut, bstk, c); break;
+            case 2: best = blas_walk<COUNT, OVF, 2, false>(pairs, tris, lo, ld, inv, go, cur, 0, 0, tLocOut, bstk, c); break;
+            case 3: best = blas_walk<COUNT, OVF, 3, false>(pairs, tris, lo, ld, inv, go, cur, 0, 0, tLocOut, bstk, c); break;
+            case 4: best = blas_walk<COUNT, OVF, 4, false>(pairs, tris, lo, ld, inv, go, cur, 0, 0, tLocOut, bstk, c); break;
+            case 5: best = blas_walk<COUNT, OVF, 5, false>(pairs, tris, lo, ld, inv, go, cur, 0, 0, tLocOut, bstk, c); break;
+            case 6: best = blas_walk<COUNT, OVF, 6, false>(pairs, tris, lo, ld, inv, go, cur, 0, 0, tLocOut, bstk, c); break;
+            case 7: best = blas_walk<COUNT, OVF, 7, false>(pairs, tris, lo, ld, inv, go, cur, 0, 0, tLocOut, bstk, c); break;
+            default: best = blas_walk<COUNT, OVF, -1, false>(pairs, tris, lo, ld, inv, go, cur, 0, 0, tLocOut, bstk, c); break;
         }
     } else
 #endif
     {
-        best = blas_walk<COUNT, OVF, -1>(pairs, tris, lo, ld, inv, go, cur, tLocOut, bstk, c);
+        best = blas_walk<COUNT, OVF, -1, false>(pairs, tris, lo, ld, inv, go, cur, 0, 0, tLocOut, bstk, c);
     }
     return best < 0 ? -1 : best + triBase;
+}
+
+// Every lane enters ITS OWN instance (record `inst` of K.instances, fetched per lane): one BLAS walk serves lanes that
+// stand in different instances.  Per lane the same operations as traverse_blas.
+template <bool COUNT, bool OVF>
+__device__ __forceinline__ int traverse_blas_mi(const KParams& K, int inst, v3 lo, v3 ld, float& tLocOut, const BlasStackT<OVF>& bstk, Tally& c) {
+    const v3 inv = rcp3(ld);
+    if (COUNT) c.blas_nodes += 1;            // the shader pops the root
+    const float4* __restrict__ I4 = reinterpret_cast<const float4*>(K.instances + inst);
+    const float4 r0 = I4[6], r1 = I4[7];     // rootMin[3], rootEnc | rootMax[3], pairBase
+    const int2 r2 = *reinterpret_cast<const int2*>(I4 + 8);      // triBase, flags
+    float tminRoot;
+    bool go = slab(lo, inv, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, tminRoot);
+    go = go && !(tminRoot > 1e30f) && !(r2.y & 1);
+    return blas_walk<COUNT, OVF, -1, true>(K.pairs, K.tris, lo, ld, inv, go, __float_as_int(r0.w), __float_as_int(r1.w), r2.x, tLocOut, bstk, c);
 }
 
 // FS:457-503 without a stack.  The shader's loop pops nodes in an order that does not depend on the ray: depth first,
@@ -560,6 +579,339 @@ __device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitR
     h.mat = __float_as_int(nm.w);
     h.inst = bestInst;
     return true;
+}
+
+// The same query for a wave whose rays have SPREAD over the scene -- the third and later segments of the paths (the pool
+// rounds of a compacting claim, the late rounds of a group) -- where trace_closest's economy turns into its cost: its scalar
+// cursor visits every list position some lane needs, one after the other, and serves the instances its lanes enter one after
+// the other too.  Measured on C4 (16 instances, 16 spp; profiles/r03_c4_before/): on the third segment 38 lanes of a wave
+// were alive, 15 of them entered an instance together, 7 were descending at any step -- the wave walked 4.9 instances per
+// query in turn -- and the third and fourth segments took 39 % of the traversal's wave cycles for 6 % of its queries.
+// Here every lane is on its own: it walks the pop-order list by itself (its own record fetch per step: the number of steps
+// is the longest lane's pops, not the number of positions the wave touches), parks at the first leaf it passes, and when
+// every lane is parked or through, ALL parked lanes run their BLAS walks at once, each in its own instance
+// (traverse_blas_mi); then they go on behind their leaves.  Per lane the pops, the culls against its own tHit, the instance
+// entries and their order are exactly trace_closest's: same result, same tallies; which of the two runs is a scheduling
+// decision of the caller (wave-uniform) that cannot change a bit of the image.
+template <bool COUNT, bool OVF>
+__device__ __forceinline__ bool trace_spread(const KParams& K, v3 o, v3 d, HitRec& h, const BlasStackT<OVF>& bstk, Tally& c) {
+    float tHit = 1e30f;
+    int bestTri = -1, bestInst = -1;
+    v3 bestP = mk3(0.0f, 0.0f, 0.0f);
+    if (COUNT) c.traversals += 1;
+    const v3 inv = rcp3(d);
+    const int nDfs = K.nTlasDfs;
+    int idx = 0;                    // the list position this lane visits next (>= nDfs: through)
+    int pinst = -1;                 // the instance this lane is about to enter
+    int pnext = 0, pend = 0;        // further entries of the same leaf in the TLAS index array (RayZen's own TLAS has one instance per leaf, BVH.cpp:204-208)
+    // (a lane enters an instance at most once per leaf entry of the list and every round enters at least one: the cap is a
+    //  backstop against a list that says otherwise -- a wave that never leaves this loop takes the device with it)
+    bool again;
+    int round = 0;
+    do {
+        // ---- the list: every lane without an instance to enter moves on until it has one or is through
+        unsigned long long wm = rz_ballot(pinst < 0 && idx < nDfs);
+        int steps = 0;
+        while (wm != 0ull) {
+            if (in_mask(wm)) {
+                RZ_SITE(c, 4);
+                const float4* __restrict__ R = reinterpret_cast<const float4*>(K.tlasDfs + idx);
+                const float4 r0 = R[0], r1 = R[1];                              // bmin, first | bmax, count
+                const int2 r2 = *reinterpret_cast<const int2*>(R + 2);          // skip, inst0
+                if (COUNT) c.tlas_nodes += 1;
+                float tmin;
+                const bool box = slab(o, inv, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, tmin);
+                const bool pass = box & !(tmin > tHit);
+                const int count = __float_as_int(r1.w), first = __float_as_int(r0.w);
+                if (count > 0 && pass) { pinst = r2.y; pnext = first + 1; pend = first + count; }
+                idx = (count < 0 && pass) ? idx + 1 : r2.x;
+            }
+            wm = (++steps <= nDfs) ? rz_ballot(pinst < 0 && idx < nDfs) : 0ull;     // (a lane's position strictly grows: at most nDfs steps)
+        }
+        // ---- the instances: all parked lanes at once, each in its own
+        again = rz_ballot(pinst >= 0) != 0ull;
+        if (pinst >= 0) {
+            if (COUNT) { c.tlas_leaf_indices += 1; c.instances += 1; }
+            RZ_SITE(c, 5);
+            const float4* __restrict__ I4 = reinterpret_cast<const float4*>(K.instances + pinst);
+            const float4 a0 = I4[0], a1 = I4[1], a2 = I4[2];
+            const float mi[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+            const v3 lo = x34_point(mi, o);
+            const v3 ld = normalize(x34_dir(mi, d));
+            float tLoc;
+            const int tri = traverse_blas_mi<COUNT, OVF>(K, pinst, lo, ld, tLoc, bstk, c);
+            if (tri >= 0) {
+                const float4 b0 = I4[3], b1 = I4[4], b2 = I4[5];
+                const float mf[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+                const v3 localHit = lo + ld * tLoc;              // FS:410
+                const v3 worldHit = x34_point(mf, localHit);     // FS:484
+                const float tWorld = length(worldHit - o);       // FS:485
+                if (tWorld < tHit) { tHit = tWorld; bestP = worldHit; bestTri = tri; bestInst = pinst; }
+            }
+            if (pnext < pend) { pinst = K.tlasIndices[pnext]; ++pnext; } else pinst = -1;
+        }
+    } while (again && ++round < K.traceRoundCap);
+    if (bestTri < 0) return false;
+    const float4 nm = *reinterpret_cast<const float4*>(K.triN + bestTri);
+    const v3 ln = mk3(nm.x, nm.y, nm.z);
+    h.t = tHit;
+    h.p = bestP;
+    h.n = normalize(x34_normal(K.instances[bestInst].inv, ln));
+    h.mat = __float_as_int(nm.w);
+    h.inst = bestInst;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The closest-hit queries of a POOL of paths, traced together (the pool rounds of a compacting claim, rz_kernels.hip).
+//
+// Why.  The third and later segments of the paths of a claim are compacted into a pool; round 2 worked it off 64 paths at a
+// time with trace_closest.  Those rays share nothing, and their BLAS walks differ wildly in length -- a ray that clips a
+// corner of an instance's box is through in three steps, one that grazes the mesh takes two hundred -- while a wave's walk
+// lasts as long as its longest lane's: measured on C2, descend steps of the pool rounds ran 14.7 and 9.5 lanes wide with 58
+// paths in the wave; on C4 (sixteen instances, entered one after the other) 7.1 and 3.3.  A fifth (C2) to two fifths (C4) of
+// the frame went there for 4-6 % of its queries.
+//
+// How.  A query is a sequence of list steps and BLAS walks of ONE path; nothing orders the queries of different paths.  So
+// the pool's queries advance in alternating phases:
+//   * T phase, 64 queries at a time, one lane each: walk the pop-order list (as trace_spread does) to the next leaf the ray
+//     passes and emit an ITEM (query, instance) -- or finish the query;
+//   * B phase: the items are walked by a wave whose lanes REFILL: a lane whose walk is over writes its result to its query
+//     (world-space hit, kept if strictly nearer: FS:484-486) and takes the next item from the list, so the wave's lanes stay
+//     busy until the list runs out instead of waiting for the longest walk of a fixed set of 64.
+// Per query the pops, the culls against its own tHit, the instance entries and their order are exactly trace_closest's (a
+// query has one item in flight at a time); only WHICH lane runs a step, and when, differs.  Same results, same tallies.
+// All state lives in the claim's scratch (rz_scene_dev.h: pool fields), read and written only by this wave.
+namespace poolf {      // field numbers of the pool (each field is PS consecutive dwords)
+enum : int { OX = 0, OY, OZ, DX, DY, DZ, TPX, TPY, TPZ, SEEDX, SEEDY, SAMP, BACK,      // the parked path (rz_kernels.hip)
+             QT = 13, QPX, QPY, QPZ, QTRI, QINST, QIDX, QSUB,                            // its query: tHit, hit point, winner, list position, entry within a multi-instance leaf
+             ITSLOT = 21, ITINST = 22 };                                                 // the items of the current B phase
+}
+static_assert(poolf::ITINST + 1 == RZ_POOL_FIELDS, "pool fields");
+
+#ifndef RZ_REFILL_MIN_LANES
+#define RZ_REFILL_MIN_LANES 8      // idle lanes it takes to interrupt the walk for a refill (unless nobody walks at all)
+#endif
+
+template <bool COUNT, bool OVF, int PS>
+__device__ __forceinline__ void pool_trace(const KParams& K, unsigned* __restrict__ pool, const int nQ, const BlasStackT<OVF>& bstk, Tally& c) {
+    using namespace poolf;
+    const int lane = threadIdx.x & 63;
+    const int nDfs = K.nTlasDfs;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int s = lane; s < nQ; s += 64) {
+        pool[QT * PS + s] = __float_as_uint(1e30f);
+        pool[QTRI * PS + s] = 0xffffffffu;
+        pool[QIDX * PS + s] = 0u;
+        pool[QSUB * PS + s] = 0u;
+    }
+    if (COUNT) for (int s = lane; s < nQ; s += 64) c.traversals += 1;
+    __syncthreads();
+    // (every iteration enters each unfinished query into one more instance, and a query enters at most K.traceRoundCap:
+    //  the bound is a backstop -- a wave that never leaves this loop takes the device with it)
+    for (int iter = 0; iter < K.traceRoundCap; ++iter) {
+        // ---- T phase
+#ifdef RZ_PROF
+        const unsigned long long tT0_ = __builtin_amdgcn_s_memtime();
+        c.rnd = 7;      // (the per-round site counters of the diagnostic build: everything pool_trace does is filed under round 7)
+#endif
+        int nItems = 0;
+        for (int sb = 0; sb < nQ; sb += 64) {
+            const int s = sb + lane;
+            int idx = s < nQ ? (int)pool[QIDX * PS + s] : nDfs;
+            unsigned long long wm = rz_ballot(idx < nDfs);
+            if (wm == 0ull) continue;
+            int sub = 0, pinst = -1;
+            v3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(1.0f, 1.0f, 1.0f);
+            float tHit = 1e30f;
+            if (idx < nDfs) {
+                o = mk3(__uint_as_float(pool[OX * PS + s]), __uint_as_float(pool[OY * PS + s]), __uint_as_float(pool[OZ * PS + s]));
+                d = mk3(__uint_as_float(pool[DX * PS + s]), __uint_as_float(pool[DY * PS + s]), __uint_as_float(pool[DZ * PS + s]));
+                tHit = __uint_as_float(pool[QT * PS + s]);
+                sub = (int)pool[QSUB * PS + s];
+            }
+            const v3 inv = rcp3(d);
+            int steps = 0;
+            while (wm != 0ull) {
+                if (in_mask(wm)) {
+                    RZ_SITE(c, 4);
+                    const float4* __restrict__ R = reinterpret_cast<const float4*>(K.tlasDfs + idx);
+                    const float4 r0 = R[0], r1 = R[1];                              // bmin, first | bmax, count
+                    const int2 r2 = *reinterpret_cast<const int2*>(R + 2);          // skip, inst0
+                    const int count = __float_as_int(r1.w), first = __float_as_int(r0.w);
+                    if (sub > 0) {      // inside a multi-instance leaf: FS:471-496 enters its instances one after the other without testing the box again
+                        pinst = K.tlasIndices[first + sub];
+                        sub = sub + 1 < count ? sub + 1 : 0;
+                        if (sub == 0) idx = r2.x;
+                    } else {
+                        if (COUNT) c.tlas_nodes += 1;
+                        float tmin;
+                        const bool box = slab(o, inv, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, tmin);
+                        const bool pass = box & !(tmin > tHit);
+                        if (count > 0 && pass) {
+                            pinst = r2.y;
+                            if (count > 1) sub = 1; else idx = r2.x;
+                        } else {
+                            idx = (count < 0 && pass) ? idx + 1 : r2.x;
+                        }
+                    }
+                }
+                wm = (++steps <= nDfs) ? rz_ballot(pinst < 0 && idx < nDfs) : 0ull;     // (a lane's position strictly grows: at most nDfs steps)
+            }
+            if (s < nQ) { pool[QIDX * PS + s] = (unsigned)idx; pool[QSUB * PS + s] = (unsigned)sub; }
+            const unsigned long long hm = rz_ballot(pinst >= 0);
+            if (pinst >= 0) {
+                const int k = nItems + __popcll(hm & below);
+                pool[ITSLOT * PS + k] = (unsigned)s;
+                pool[ITINST * PS + k] = (unsigned)pinst;
+            }
+            nItems += mask_count(hm);
+        }
+#ifdef RZ_PROF
+        const unsigned long long tB0_ = __builtin_amdgcn_s_memtime();
+        c.t[13] += tB0_ - tT0_;
+#endif
+        if (nItems == 0) break;
+        __syncthreads();
+        // ---- B phase: walk the items, lanes refilling from the list
+        int next = 0;                               // wave-uniform: the next item to hand out
+        int slot = -1, inst = 0;                    // the item this lane holds (slot < 0: none)
+        int cur = -1, sp = 0, best = -1, pbase = 0, tbase = 0;
+        float tLoc = 1e30f;
+        v3 lo = mk3(0.0f, 0.0f, 0.0f), ld = mk3(1.0f, 1.0f, 1.0f);
+        RayPk RP = make_raypk(lo, ld);
+        // (an item is walked in fewer than 2 x its BLAS's nodes rounds -- the host has checked that the node arrays are trees --
+        //  and every refill hands out or retires an item: the bound is a backstop)
+        bool again;
+        unsigned guard = 0;
+        do {
+            // -- refill: idle lanes retire the item they hold and take the next one
+            bool idle = cur == -1 && sp == 0;
+            unsigned long long im = rz_ballot(idle);
+            bool refill = (next < nItems || rz_ballot(idle && slot >= 0) != 0ull) &&
+                          (mask_count(im) >= RZ_REFILL_MIN_LANES || rz_ballot(!idle) == 0ull);
+#ifdef RZ_PROF
+            const unsigned long long tR0_ = __builtin_amdgcn_s_memtime();
+            RZ_SITE(c, 0);              // rounds of the B phase and the lanes in them
+            if (refill && idle) RZ_SITE(c, 1);     // refill events and the idle lanes they serve
+#endif
+            while (refill) {
+                const int pending = nItems - next;
+                if (idle) {
+                    if (slot >= 0 && best >= 0) {       // FS:410, 484-486: the hit in world space, kept if strictly nearer
+                        const float4* __restrict__ I4 = reinterpret_cast<const float4*>(K.instances + inst);
+                        const float4 b0 = I4[3], b1 = I4[4], b2 = I4[5];
+                        const float mf[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+                        const v3 o = mk3(__uint_as_float(pool[OX * PS + slot]), __uint_as_float(pool[OY * PS + slot]), __uint_as_float(pool[OZ * PS + slot]));
+                        const v3 localHit = lo + ld * tLoc;
+                        const v3 worldHit = x34_point(mf, localHit);
+                        const float tWorld = length(worldHit - o);
+                        if (tWorld < __uint_as_float(pool[QT * PS + slot])) {
+                            pool[QT * PS + slot] = __float_as_uint(tWorld);
+                            pool[QPX * PS + slot] = __float_as_uint(worldHit.x); pool[QPY * PS + slot] = __float_as_uint(worldHit.y); pool[QPZ * PS + slot] = __float_as_uint(worldHit.z);
+                            pool[QTRI * PS + slot] = (unsigned)best;
+                            pool[QINST * PS + slot] = (unsigned)inst;
+                        }
+                    }
+                    slot = -1;
+                    const int rank = __popcll(im & below);
+                    if (rank < pending) {
+                        const int k = next + rank;
+                        slot = (int)pool[ITSLOT * PS + k];
+                        inst = (int)pool[ITINST * PS + k];
+                        if (COUNT) { c.tlas_leaf_indices += 1; c.instances += 1; c.blas_nodes += 1; }
+                        RZ_SITE(c, 5);
+                        const v3 o = mk3(__uint_as_float(pool[OX * PS + slot]), __uint_as_float(pool[OY * PS + slot]), __uint_as_float(pool[OZ * PS + slot]));
+                        const v3 d = mk3(__uint_as_float(pool[DX * PS + slot]), __uint_as_float(pool[DY * PS + slot]), __uint_as_float(pool[DZ * PS + slot]));
+                        const float4* __restrict__ I4 = reinterpret_cast<const float4*>(K.instances + inst);
+                        const float4 a0 = I4[0], a1 = I4[1], a2 = I4[2];
+                        const float mi[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+                        lo = x34_point(mi, o);
+                        ld = normalize(x34_dir(mi, d));
+                        const v3 linv = rcp3(ld);
+                        const float4 r0 = I4[6], r1 = I4[7];                         // rootMin[3], rootEnc | rootMax[3], pairBase
+                        const int2 r2 = *reinterpret_cast<const int2*>(I4 + 8);      // triBase, flags
+                        float tminRoot;
+                        bool go = slab(lo, linv, r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, tminRoot);
+                        go = go && !(tminRoot > 1e30f) && !(r2.y & 1);
+                        cur = go ? __float_as_int(r0.w) : -1;
+                        pbase = __float_as_int(r1.w); tbase = r2.x;
+                        RP = make_raypk(lo, linv);
+                        tLoc = 1e30f; best = -1; sp = 0;
+                    }
+                }
+                next += pending < mask_count(im) ? pending : mask_count(im);
+                idle = cur == -1 && sp == 0;
+                im = rz_ballot(idle);
+                // (again at once if the lanes just served are idle already -- their rays missed the root box -- and items remain)
+                refill = next < nItems && (mask_count(im) >= RZ_REFILL_MIN_LANES || rz_ballot(!idle) == 0ull);
+            }
+#ifdef RZ_PROF
+            c.t[15] += __builtin_amdgcn_s_memtime() - tR0_;
+#endif
+            // -- descend (the loops of blas_walk<.., MI = true>)
+            unsigned long long actMask = rz_ballot(cur >= 0);
+            bool more = actMask != 0ull;
+            while (more) {
+                if (in_mask(actMask)) {
+                    RZ_SITE(c, 3);
+                    if (COUNT) c.blas_nodes += 2;
+                    const float4* __restrict__ p4 = reinterpret_cast<const float4*>(K.pairs + (pbase + cur));
+                    float4 p0 = p4[0], p1 = p4[1], p2 = p4[2], p3 = p4[3];
+                    RZ_KEEP4(p0); RZ_KEEP4(p3);
+                    const f32x2 lx = {p0.x, p0.y}, ly = {p0.z, p0.w}, lz = {p1.x, p1.y};
+                    const f32x2 rx = {p1.z, p1.w}, ry = {p2.x, p2.y}, rz = {p2.z, p2.w};
+                    float tl, tr;
+                    bool hl, hr;
+                    RZ_SLAB_PAIR(-1, RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
+                    const int lenc = __float_as_int(p3.x), renc = __float_as_int(p3.y);
+                    const bool takeR = hr && !(tr > tLoc);
+                    if (hl && takeR) push_entry(bstk, sp, make_uint2((unsigned)lenc, __float_as_uint(tl)));
+                    int nxt = takeR ? renc : ((tl > tLoc) ? -1 : lenc);
+                    if (!hl && !takeR) {
+                        if (!pop_entry(bstk, sp, tLoc, nxt)) nxt = -1;
+                    }
+                    cur = nxt;
+                }
+                actMask = rz_ballot(cur >= 0);
+                more = mask_count(actMask) >= RZ_DESCEND_MIN_LANES;
+            }
+            // -- leaves
+            again = rz_ballot((cur != -1) || (sp > 0)) != 0ull;
+            if (again) {
+                const bool leaf = cur < 0;
+                const int v = ~cur;
+                const int first = (v >> 4) + tbase, count = leaf ? (v & 15) : 0;
+                if (COUNT) c.triangles += (unsigned)count;
+                int i = 0;
+                unsigned long long triMask = rz_ballot(0 < count);
+                bool any = triMask != 0ull;
+                while (any) {
+                    if (in_mask(triMask)) {
+                        RZ_SITE(c, 2);
+                        const float4* __restrict__ tp = reinterpret_cast<const float4*>(K.tris + first + i);
+                        float4 a = tp[0], b = tp[1], cc = tp[2];
+                        RZ_KEEP4(a);
+                        float t;
+                        const bool hit = moller_trumbore(lo, ld, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, cc.x), t);
+                        if (hit && t < tLoc) { tLoc = t; best = first + i; }
+                    }
+                    ++i;
+                    triMask = rz_ballot(i < count);
+                    any = triMask != 0ull;
+                }
+                if (leaf) {
+                    if (!pop_entry(bstk, sp, tLoc, cur)) cur = -1;
+                }
+            }
+            // (nobody walks: go on while items remain or a lane still holds a finished one)
+            again = again || next < nItems || rz_ballot(slot >= 0) != 0ull;
+        } while (again && ++guard < (1u << 28));
+#ifdef RZ_PROF
+        c.t[14] += __builtin_amdgcn_s_memtime() - tB0_;
+#endif
+        __syncthreads();
+    }
 }
 
 }  // namespace rz

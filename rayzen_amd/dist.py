@@ -162,6 +162,13 @@ class Group:
         self._check(self._L.rz_group_read_frame(self._g, out.ctypes.data, out.nbytes), "rz_group_read_frame")
         return out
 
+    def last_reduce_ms(self):
+        """(ms on the root member or -1, longest ms over this process's members) of the last reduce (HIP events)."""
+        import ctypes as C
+        a, b = C.c_float(0), C.c_float(0)
+        self._check(self._L.rz_group_last_reduce_ms(self._g, C.byref(a), C.byref(b)), "rz_group_last_reduce_ms")
+        return float(a.value), float(b.value)
+
     def frame_device_ptr(self):
         return self._L.rz_group_frame_device_ptr(self._g)
 

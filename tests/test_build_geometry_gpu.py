@@ -66,6 +66,46 @@ def test_build_geometry_argument_checks():
     r.close()
 
 
+def test_a_failed_build_leaves_the_previous_geometry_intact():
+    """rz_build_geometry used to write mesh after mesh into the context's own node / index arrays, so a call that
+    failed half-way (here: std::bad_alloc injected at the second mesh by the allocation hook) left `geometry on the device`
+    describing arrays that now held part of another build -- rz_read_binding returned garbage without an error.  It builds
+    into fresh buffers and swaps on success: after the failure the context reads back and renders the FIRST build."""
+    cam = S.Camera(position=(0.0, 5.0, 12.0), target=(0.0, -0.35, -1.0), aspect=16 / 9)
+    meshes, objects = _scene_parts(10, 4)
+    ref = _host_scene(meshes, objects, cam)
+    r = Renderer(0)
+    r.upload_scene_built_on_device(meshes, objects, ref.materials, ref.lights)
+    W, H, spp, bn = 80, 45, 2, 4
+    r.set_frame(frame_params(cam, W, H, len(ref.lights), bn, spp))
+    want = oracle_render(ref, W, H, spp, bn)
+    r.render()
+    assert (r.read_accum().view(np.uint32) == want.view(np.uint32)).all()
+    # a different, larger set of meshes; the hook throws at the 2nd allocation site = after the first mesh has been built
+    other = [S.make_blob(14, 3.0, 1, seed=3), S.make_blob(9, 1.0, 0, seed=5), S.make_cube(2)]
+    tris = np.concatenate(other)
+    ranges, first = [], 0
+    for m in other:
+        ranges.append((first, len(m)))
+        first += len(m)
+    for nth in (1, 2, 3):
+        r.debug_fail_alloc(nth)
+        with pytest.raises(RayZenError) as e:
+            r.build_geometry(tris, ranges)
+        assert e.value.code == -8, e.value
+        r.debug_fail_alloc(0)
+        assert r.read_binding(S.BIND_BLAS_NODES).tobytes() == ref.arrays[S.BIND_BLAS_NODES].tobytes()
+        assert r.read_binding(S.BIND_BLAS_INDICES).tobytes() == ref.arrays[S.BIND_BLAS_INDICES].tobytes()
+        assert r.read_binding(S.BIND_TRIANGLES).tobytes() == ref.arrays[S.BIND_TRIANGLES].tobytes()
+        r.clear_accum()
+        r.render()
+        assert (r.read_accum().view(np.uint32) == want.view(np.uint32)).all()
+    # and the same call succeeds once the hook is off
+    built = r.build_geometry(tris, ranges)
+    assert [b["n_nodes"] > 0 for b in built] == [True, True, True]
+    r.close()
+
+
 def test_one_million_triangles_device_resident_timing():
     """Not pass/fail on time: prints what the geometry half of scene assembly costs each way (DESIGN.md quotes it)."""
     import time

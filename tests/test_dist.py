@@ -121,3 +121,56 @@ def test_repeated_steps_reduce_to_the_same_frame(tmp_path):
     want = oracle_render(S.cornell_scene(), 40, 24, 2, 2, nthreads=2)
     for f in frames:
         assert (f.view(np.uint32) == want.view(np.uint32)).all()
+
+
+# ---- bench.py --gpus N started as ONE plain process -----------------------------------------------
+
+def _bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rz_bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_launch_mode_of_the_bench():
+    b = _bench()
+    assert b.launch_mode(1, {}) == "single"
+    assert b.launch_mode(8, {}) == "local-group"                        # `python3 bench.py --gpus 8`: no launcher, no re-exec
+    assert b.launch_mode(8, {"WORLD_SIZE": "8", "RANK": "3"}) == "ranks"  # torch.distributed.run: one process per GPU
+    assert b.launch_mode(1, {"WORLD_SIZE": "1"}) == "single"
+    with pytest.raises(SystemExit):
+        b.launch_mode(4, {"WORLD_SIZE": "8"})
+
+
+def test_bench_with_gpus_2_and_no_launcher_reaches_the_one_process_group(monkeypatch):
+    """`python3 bench.py --gpus 2` with WORLD_SIZE unset used to exit with "launch N > 1 with torch.distributed.run".  It now
+    takes the library's one-process group: rz_group_create(2) (ncclCommInitAll) -- no torch.distributed, no second process.
+    There is no GPU here, so the device count and the group constructor are stand-ins: the test asserts that main() gets as
+    far as Group.create(2, ...) and that no process group was initialised on the way."""
+    import torch.distributed as dist
+    from rayzen_amd import _lib, dist as rzdist
+    b = _bench()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+
+    class Reached(Exception):
+        pass
+
+    seen = {}
+
+    def fake_create(cls, ndev, devices=None, flags=0):
+        seen["ndev"], seen["devices"] = ndev, devices
+        raise Reached()
+
+    monkeypatch.setattr(_lib.hip(), "rz_device_count", lambda: 2)
+    monkeypatch.setattr(rzdist.Group, "create", classmethod(fake_create))
+    with pytest.raises(Reached):
+        b.main(["--gpus", "2", "--steps", "1", "--warmup", "0", "--mesh-n", "4", "--width", "64", "--height", "32", "--no-cpu-baseline"])
+    assert seen == {"ndev": 2, "devices": None}
+    assert not dist.is_initialized()
+    # fewer devices than ranks: a clear refusal, not a hang
+    monkeypatch.setattr(_lib.hip(), "rz_device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        b.main(["--gpus", "2", "--no-cpu-baseline"])
+    assert "only 1 HIP device" in str(e.value)

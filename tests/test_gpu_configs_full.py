@@ -75,6 +75,8 @@ def test_c4_full_size_sixteen_instances_dynamic():
         r.update_dynamic(sc)
         r.render_scene(sc, W, H, spp, b)
         gpu = r.read_accum()
+        plan = r.debug_last_plan()      # 16 spp: 4 pixels per wave, and at 518 400 groups the persistent, compacting grid (round 3)
+        assert plan["pixels_per_wave"] == 4 and plan["per_claim"] > 0 and plan["claim_units"] in (8, 16), plan
         assert np.isfinite(gpu).all() and (gpu >= 0).all() and (gpu[..., 3] == spp).all()
         bands = (304, 520, 736)
         ref = _oracle_bands(sc, W, H, spp, b, bands, rows=16)
@@ -246,6 +248,55 @@ def test_compacting_launch_counters_equal_the_oracle_s():
     W, H, spp, b = 1280, 1024, 64, 4
     img, cnt = hip_render(sc, W, H, spp, b, counted=True)
     osc, fr = oracle_scene(sc), oracle_frame(sc, W, H, spp, b)
+    ref = np.zeros_like(img)
+    _, rc = rzo.render(osc, fr, accum=ref, nthreads=16, want_counters=True)
+    assert cnt == rc
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+# ---- the compacting launch for FEWER than 64 samples per pixel (round 3): a unit is a group of 64 / spp pixels -----------
+
+@pytest.mark.parametrize("W,H,spp,claim", [(640, 512, 16, 8), (643, 509, 5, 8), (640, 512, 24, 4), (320, 256, 1, 8), (323, 253, 2, 3),
+                                           (640, 512, 48, 16), (331, 259, 63, 7), (640, 512, 32, 1)])
+def test_compacting_launch_below_64_spp_equals_the_plain_one_and_the_oracle(W, H, spp, claim, monkeypatch):
+    """spp < 64: a wave holds 64 / spp pixels (a compact block of the tile) and a claim is `claim` such groups.  Sample
+    counts that divide 64 and ones that do not (5 -> 12 pixels per group, which straddle tiles; 24, 48, 63 -> idle lanes),
+    frames that are / are not multiples of the tile, claims that do not divide a tile: claims on == one workgroup per
+    group == oracle band, and the launch plan says which of the two ran.  (Small frames do not take the persistent grid
+    by themselves: RZ_GROUPS_PER_CLAIM forces it, as in the odd-claims test above; C4's full-size test takes it unforced.)
+    Reference semantics: fragment_shader.glsl:668-773."""
+    from rayzen_amd.renderer import Renderer
+    sc = S.bunny_scene(n=16, aspect=W / H)
+    b = 5
+    plain = hip_render(sc, W, H, spp, b)
+    monkeypatch.setenv("RZ_GROUPS_PER_CLAIM", str(claim))
+    r = Renderer(0)
+    on = hip_render(sc, W, H, spp, b, renderer=r)
+    plan = r.debug_last_plan()
+    r.close()
+    monkeypatch.delenv("RZ_GROUPS_PER_CLAIM")
+    assert plan["per_claim"] == claim and plan["claim_units"] in (8, 16) and plan["pixels_per_wave"] == 64 // spp, plan
+    assert (on.view(np.uint32) == plain.view(np.uint32)).all(), mismatch_report(on, plain)
+    assert (on[..., 3] == spp).all()
+    _band_check(sc, W, H, spp, b, on)
+
+
+def test_compacting_launch_below_64_spp_continued_frames_tile_ranks_and_counters(monkeypatch):
+    sc = S.bunny_scene(n=12, aspect=1280 / 1024)
+    W, H, b = 1280, 1024, 4
+    monkeypatch.setenv("RZ_GROUPS_PER_CLAIM", "8")
+    whole = hip_render(sc, W, H, 48, b)
+    # 48 spp as three continued calls of 16 (sample_base > 0 reads the accumulation buffer back in the claim's sum pass)
+    three = hip_render(sc, W, H, 48, b, chunk=16)
+    # ... which is NOT the same image as one 48-spp call would be only if a sample's arithmetic depended on its lane: it does not
+    assert (three.view(np.uint32) == whole.view(np.uint32)).all(), mismatch_report(three, whole)
+    total = np.zeros_like(whole)
+    for k in range(3):
+        total += hip_render(sc, W, H, 48, b, tile_rank=k, tile_nranks=3)
+    assert (total.view(np.uint32) == whole.view(np.uint32)).all()
+    img, cnt = hip_render(sc, W, H, 16, b, counted=True)
+    monkeypatch.delenv("RZ_GROUPS_PER_CLAIM")
+    osc, fr = oracle_scene(sc), oracle_frame(sc, W, H, 16, b)
     ref = np.zeros_like(img)
     _, rc = rzo.render(osc, fr, accum=ref, nthreads=16, want_counters=True)
     assert cnt == rc
