@@ -1,0 +1,22 @@
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r3j; mkdir -p $O
+timeout -k 10 600 python3 -m pytest tests/test_gpu_configs_full.py -x -q -m gpu -k "global_pool or compacting" > $O/gpu_tests.log 2>&1 || { tail -40 $O/gpu_tests.log; exit 1; }
+tail -3 $O/gpu_tests.log
+run() { echo "== $*" >> $O/ab.log; env "$@" timeout -k 10 300 python3 profiles/scripts/config_ms.py $CFG >> $O/ab.log 2>&1 || exit 1; }
+CFG="c2 c4 c5 c5full c3"
+run RAYZEN_HIP_SO=$PWD/rayzen_amd/lib/librayzen_hip_base.so
+run A=1
+run RZ_GLOBAL_POOL=0
+CFG="c4"
+run RZ_SMALL_SPP_CLAIMS=0
+for pc in 4 8 16; do run RZ_GROUPS_PER_CLAIM=$pc; done
+cat $O/ab.log
+for w in c2 c4; do
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -o run -- python3 profiles/scripts/one_frame.py $w > $O/kt_$w.log 2>&1
+python3 - <<PY
+import csv
+rows=list(csv.DictReader(open("$O/kt_$w/run_kernel_stats.csv")))
+for r in rows[:3]: print("$w", r["Name"][:70], r["Calls"], "avg us %.1f"%(float(r["AverageNs"])/1e3), "tot ms %.3f"%(float(r["TotalDurationNs"])/1e6))
+PY
+done

@@ -211,6 +211,12 @@ __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
 #ifndef RZ_CLAIM_RUN_SMALL_SPP
 #define RZ_CLAIM_RUN_SMALL_SPP 1
 #endif
+#ifndef RZ_CROSS_POOL_MIN_UNITS
+#define RZ_CROSS_POOL_MIN_UNITS (256ll << 10)
+#endif
+#ifndef RZ_PARK_BOUNCE
+#define RZ_PARK_BOUNCE 2         // a path is parked when it stands in front of this segment (0-based: its third)
+#endif
 #ifndef RZ_COMPACT_DEFAULT
 #define RZ_COMPACT_DEFAULT 1     // compaction of late bounces across a claim (render_claim_compact); RZ_COMPACT=0/1 overrides at run time
 #endif
@@ -528,6 +534,69 @@ struct ClaimMap {
     }
 };
 
+// The ordered sums of a claim's pixels from its addends ([unit][6][64] floats at addBase): 21 pixels per pass, lane 3 q + ch
+// replays the additions of channel ch of the pass's q-th pixel in sample order, FS:717 then FS:709, sample after sample
+// (spp >= 64: a claim has at most 16 pixels -- one pass, 24 or 48 lanes busy; spp < 64: up to 64 pixels per unit, each summing
+// its spp entries of one unit's addends).  Run at the end of a claim, or by rz_deferred_sums once the claim's parked paths
+// have come back from the launch's global pool.
+template <bool COUNT>
+__device__ __forceinline__ void claim_ordered_sums(const KParams& K, const ClaimMap& M, const unsigned ci, const float* __restrict__ addBase,
+                                                   const int nPix, const int ppw, const int nBatches) {
+    const int lane = threadIdx.x & 63;
+    const int spp = K.spp;
+    for (int p0 = 0; p0 < nPix; p0 += 21) {
+        const int q = lane / 3, ch = lane - 3 * q;
+        const int p = p0 + q;
+        bool inside = false;
+        size_t pix = 0;
+        float chan = 0.0f, alpha = 0.0f;
+        if (q < 21 && p < nPix) {
+            const int gq = p / ppw;
+            const int slot = M.group(ci, gq) * ppw + (p - gq * ppw);
+            const int localTile = slot >> 6, l = slot & 63;
+            const int tile = localTile * K.tileNRanks + K.tileRank;
+            const int ty = tile / K.tilesX, tx = tile - ty * K.tilesX;
+            const int px = tx * RZ_TILE_W + slot_x(l, spp < 64), py = ty * RZ_TILE_H + slot_y(l, spp < 64);
+            if (slot < K.nSlots && px < K.width && py < K.height) {
+                inside = true;
+                pix = (size_t)py * K.width + px;
+                if (K.sampleBase != 0) {
+                    const float4 a = K.accum[pix];
+                    chan = ch == 0 ? a.x : (ch == 1 ? a.y : a.z);
+                    alpha = a.w;
+                }
+            }
+        }
+        if (inside) {
+            const int g = p / ppw, lane0 = (p - g * ppw) * spp;      // spp < 64: the pixel's unit and its first lane there
+            for (int b = 0; b < nBatches; ++b) {
+                const float* Lf = addBase + (size_t)(spp >= 64 ? p * nBatches + b : g) * 384 + 64 * ch + (spp >= 64 ? 0 : lane0);
+                const float* Sf = Lf + 192;
+                const int n = spp >= 64 ? min(64, spp - b * 64) : spp;
+                int k = 0;
+                for (; k + 8 <= n; k += 8) {
+                    float l[8], q8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { l[u] = Lf[k + u]; q8[u] = Sf[k + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { chan = chan + l[u]; chan = chan + q8[u]; }   // FS:717, FS:709
+                }
+                for (; k < n; ++k) { chan = chan + Lf[k]; chan = chan + Sf[k]; }
+            }
+        }
+        const int l0 = q < 21 ? 3 * q : 0;
+        const float cx = __shfl(chan, l0), cy = __shfl(chan, l0 + 1), cz = __shfl(chan, l0 + 2);
+        if (inside && ch == 0) {
+            K.accum[pix] = make_float4(cx, cy, cz, alpha + (float)spp);
+            K.ior[pix] = 1.0f;
+        }
+        if (COUNT) {
+            const unsigned long long im = rz_ballot(inside && ch == 0);
+            if (lane == 0 && im) atomicAdd(&K.counters->pixels, (unsigned long long)__popcll(im));
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // render_claim_compact: the opaque spp >= 64 persistent path with RAY COMPACTION across the pixels of a claim
 // (north_star: "wavefront ballot / prefix-sum ray compaction for divergent bounces").
@@ -543,13 +612,18 @@ struct ClaimMap {
 // Scratch is private to the resident wave and is only ever read by the wave that wrote it (L1/L2 hits); the
 // __syncthreads() of the one-wave workgroup order its stores before its loads.
 template <bool COUNT, bool OVF, int UNITS>
-__device__ __forceinline__ void render_claim_compact(const KParams& K, const ClaimMap M, const unsigned ci, unsigned char* lds_raw) {
+__device__ __forceinline__ void render_claim_compact(const KParams& K, const ClaimMap M, const unsigned ci, unsigned char* lds_raw, int& wpN) {
     const int lane = threadIdx.x & 63;
     const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + lane,
                                OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + lane : nullptr, K.blasStackCap};
     float* const addBase = K.claimScratch + (size_t)blockIdx.x * K.claimStride;
     unsigned* const pool = reinterpret_cast<unsigned*>(addBase + (size_t)UNITS * 6 * 64);
     constexpr int PS = UNITS * 64;                    // pool stride (slots per field)
+    // the wave's pool ACROSS claims (large launches): paths are parked there, behind the wpN it already holds, and the claim
+    // does not work them off itself (pool_process, when the pool has filled up)
+    const bool crossClaim = K.wpool != nullptr;
+    unsigned* const W = crossClaim ? K.wpool + (size_t)blockIdx.x * K.wpoolStride * RZ_GPOOL_FIELDS : nullptr;
+    const size_t WS = K.wpoolStride;
     const int spp = K.spp;
     const int nBatches = (spp + 63) / 64;
     // a unit is one wave's worth of samples: a 64-sample batch of one pixel (spp >= 64), or all spp samples of each of the
@@ -565,6 +639,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
     Tally c = {};
     unsigned guard = 0;
     bool cont;
+    bool claimDeferred = false;     // wave-uniform: the claim's parked paths went to the launch's global pool (its pixels are summed later)
     do {                                                        // (one exit, at the end: see blas_walk; the bound is a backstop: units + pool rounds of at most maxBounces generations)
         const bool phase2 = unit >= nUnits;
         Path P;         // (per round: nothing of a path lives across rounds -- declared outside, all its fields stayed allocated across pool_trace)
@@ -573,18 +648,6 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
 #endif
         int backUnit = 0, backLane = lane;
         bool poolLane = false;
-        int qTri = -1, qInst = 0;               // phase 2: the winner of this lane's query (pool_trace)
-        if (phase2 && poolBase == 0) {
-            // a generation of the pool starts: ALL its closest-hit queries are traced together, the lanes refilling from the
-            // list of pending BLAS walks (rz_trace.h: pool_trace); the rounds below only shade the results, 64 paths at a time
-#ifdef RZ_PROF
-            const unsigned long long tpt0_ = __builtin_amdgcn_s_memtime();
-#endif
-            pool_trace<COUNT, OVF, PS>(K, pool, nPool, bstk, c);
-#ifdef RZ_PROF
-            c.t[12] += __builtin_amdgcn_s_memtime() - tpt0_;
-#endif
-        }
         P.mode = MODE_DONE;
         P.addLight = mk3(0.0f, 0.0f, 0.0f);
         P.addSky = mk3(0.0f, 0.0f, 0.0f);
@@ -636,16 +699,11 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
                 backLane = (int)(bb & 63u);
                 P.color = mk3(0.0f, 0.0f, 0.0f);
                 P.mode = MODE_SEGMENT;
-                qTri = (int)pool[poolf::QTRI * PS + sl];
-                qInst = (int)pool[poolf::QINST * PS + sl];
             }
         }
         // ONE trace / advance loop serves both phases.  Phase 1: a unit's paths run until they finish or stand in front
         // of their third segment (bounce >= 2).  Phase 2: every pooled path runs exactly one segment (there are no shadow
         // queries after bounce 0), so the survivors can be compacted again before the next bounce.
-#ifndef RZ_PARK_BOUNCE
-#define RZ_PARK_BOUNCE 2
-#endif
         const int stopBounce = phase2 ? P.bounce + 1 : RZ_PARK_BOUNCE;
         // (one exit, at the end of the body: see blas_walk)
         bool run = P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= stopBounce);
@@ -660,23 +718,10 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
                 RZ_SITE(c, 6);
                 const unsigned long long tq0_ = __builtin_amdgcn_s_memtime();
 #endif
-                bool found;
-                if (!phase2) {
-                    found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, c);
-                } else {
-                    // the query was traced with the rest of its generation: its winner's point, normal and material, as at the end
-                    // of trace_closest (FS:411-412, 489-491)
-                    found = qTri >= 0;
-                    if (found) {
-                        const int sl = poolBase + lane;
-                        const float4 nm = *reinterpret_cast<const float4*>(K.triN + qTri);
-                        h.t = __uint_as_float(pool[poolf::QT * PS + sl]);
-                        h.p = mk3(__uint_as_float(pool[poolf::QPX * PS + sl]), __uint_as_float(pool[poolf::QPY * PS + sl]), __uint_as_float(pool[poolf::QPZ * PS + sl]));
-                        h.n = normalize(x34_normal(K.instances[qInst].inv, mk3(nm.x, nm.y, nm.z)));
-                        h.mat = __float_as_int(nm.w);
-                        h.inst = qInst;
-                    }
-                }
+                // (a claim's own pool -- small launches, and claims that found the launch's global pool full -- is worked off 64
+                //  paths at a time by the wave-cursor walk, as in round 2; the lane-refilling tracer needs a list much longer than
+                //  a claim's few dozen paths: rz_late_generation)
+                const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, c);
 #ifdef RZ_PROF
                 c.rt[c.rnd & 7] += __builtin_amdgcn_s_memtime() - tq0_;
 #endif
@@ -701,21 +746,37 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
         }
         // compaction: parked lane -> pool slot (write cursor) + (number of parked lanes below it).  In phase 2 the write
         // cursor trails the read cursor (a round reads 64 slots and parks at most 64), so the pool is compacted in place.
-        const int wbase = phase2 ? poolWrite : nPool;
+        const int wbase = phase2 ? poolWrite : (crossClaim ? wpN + nPool : nPool);
         if (parked) {
             const int sl = wbase + __popcll(pm & ((1ull << lane) - 1ull));
-            pool[0 * PS + sl] = __float_as_uint(P.o.x); pool[1 * PS + sl] = __float_as_uint(P.o.y); pool[2 * PS + sl] = __float_as_uint(P.o.z);
-            pool[3 * PS + sl] = __float_as_uint(P.d.x); pool[4 * PS + sl] = __float_as_uint(P.d.y); pool[5 * PS + sl] = __float_as_uint(P.d.z);
-            pool[6 * PS + sl] = __float_as_uint(P.throughput.x); pool[7 * PS + sl] = __float_as_uint(P.throughput.y);
-            pool[8 * PS + sl] = __float_as_uint(P.throughput.z);
-            pool[9 * PS + sl] = __float_as_uint(P.seed.x); pool[10 * PS + sl] = __float_as_uint(P.seed.y);
-            pool[11 * PS + sl] = (unsigned)P.samp;
-            pool[12 * PS + sl] = ((unsigned)P.bounce << 16) | ((unsigned)backUnit << 6) | (unsigned)backLane;
+            unsigned* const Q = crossClaim ? W : pool;
+            const size_t qs = crossClaim ? WS : (size_t)PS;
+            Q[0 * qs + sl] = __float_as_uint(P.o.x); Q[1 * qs + sl] = __float_as_uint(P.o.y); Q[2 * qs + sl] = __float_as_uint(P.o.z);
+            Q[3 * qs + sl] = __float_as_uint(P.d.x); Q[4 * qs + sl] = __float_as_uint(P.d.y); Q[5 * qs + sl] = __float_as_uint(P.d.z);
+            Q[6 * qs + sl] = __float_as_uint(P.throughput.x); Q[7 * qs + sl] = __float_as_uint(P.throughput.y);
+            Q[8 * qs + sl] = __float_as_uint(P.throughput.z);
+            Q[9 * qs + sl] = __float_as_uint(P.seed.x); Q[10 * qs + sl] = __float_as_uint(P.seed.y);
+            Q[11 * qs + sl] = (unsigned)P.samp;
+            Q[12 * qs + sl] = ((unsigned)P.bounce << 16) | ((unsigned)backUnit << 6) | (unsigned)backLane;
+            if (crossClaim) Q[(size_t)(RZ_GPOOL_FIELDS - 1) * qs + sl] = ci;
         }
+        bool deferred = false;
         if (!phase2) {
             nPool += __popcll(pm);
             ++unit;
-            if (unit >= nUnits) __syncthreads();       // the pool is read next
+            if (unit >= nUnits) {
+                __syncthreads();       // the pool is read next
+                if (crossClaim && nPool > 0) {
+                    // the claim's pixels wait for its parked paths: its addends move to the launch's buffer (rz_deferred_sums
+                    // adds them up when every path is back) and the wave goes on to its next claim
+                    float* const D = K.daddends + (size_t)ci * K.dClaimStride;
+                    for (int k = lane; k < nUnits * 384; k += 64) D[k] = addBase[k];
+                    if (lane == 0) K.dflags[ci] = 1;
+                    wpN += nPool;
+                    deferred = true;
+                    claimDeferred = true;
+                }
+            }
         } else {
             poolWrite += __popcll(pm);
             poolBase += 64;
@@ -727,8 +788,8 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
             else { c.t[4] += dt_; }
         }
 #endif
-        cont = true;
-        if (unit >= nUnits && poolBase >= nPool) {      // this generation is through: the paths it left behind form the next one
+        cont = !deferred;
+        if (cont && unit >= nUnits && poolBase >= nPool) {      // this generation is through: the paths it left behind form the next one
             if (poolWrite == 0) {
                 cont = false;
             } else {
@@ -738,64 +799,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
         }
     } while (cont && ++guard < (1u << 20));
     __syncthreads();
-    // ---- the claim's ordered sums: 21 pixels per pass, lane 3 q + ch replays the additions of channel ch of the pass's q-th
-    // pixel in sample order (spp >= 64: a claim has at most 16 pixels -- one pass, 24 or 48 lanes busy; spp < 64: up to 64
-    // pixels per unit, each summing its spp entries of one unit's addends)
-    for (int p0 = 0; p0 < nPix; p0 += 21) {
-        const int q = lane / 3, ch = lane - 3 * q;
-        const int p = p0 + q;
-        bool inside = false;
-        size_t pix = 0;
-        float chan = 0.0f, alpha = 0.0f;
-        if (q < 21 && p < nPix) {
-            const int gq = p / ppw;
-            const int slot = M.group(ci, gq) * ppw + (p - gq * ppw);
-            const int localTile = slot >> 6, l = slot & 63;
-            int tx = tileX, ty = tileY;         // the last unit's tile: the right one unless the claim straddles two tiles
-            if (localTile != tileCached) {
-                const int tile = localTile * K.tileNRanks + K.tileRank;
-                ty = tile / K.tilesX;
-                tx = tile - ty * K.tilesX;
-            }
-            const int px = tx * RZ_TILE_W + slot_x(l, spp < 64), py = ty * RZ_TILE_H + slot_y(l, spp < 64);
-            if (slot < K.nSlots && px < K.width && py < K.height) {
-                inside = true;
-                pix = (size_t)py * K.width + px;
-                if (K.sampleBase != 0) {
-                    const float4 a = K.accum[pix];
-                    chan = ch == 0 ? a.x : (ch == 1 ? a.y : a.z);
-                    alpha = a.w;
-                }
-            }
-        }
-        if (inside) {
-            const int g = p / ppw, lane0 = (p - g * ppw) * spp;      // spp < 64: the pixel's unit and its first lane there
-            for (int b = 0; b < nBatches; ++b) {
-                const float* Lf = addBase + (size_t)(spp >= 64 ? p * nBatches + b : g) * 384 + 64 * ch + (spp >= 64 ? 0 : lane0);
-                const float* Sf = Lf + 192;
-                const int n = spp >= 64 ? min(64, spp - b * 64) : spp;
-                int k = 0;
-                for (; k + 8 <= n; k += 8) {
-                    float l[8], q8[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { l[u] = Lf[k + u]; q8[u] = Sf[k + u]; }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { chan = chan + l[u]; chan = chan + q8[u]; }   // FS:717, FS:709
-                }
-                for (; k < n; ++k) { chan = chan + Lf[k]; chan = chan + Sf[k]; }
-            }
-        }
-        const int l0 = q < 21 ? 3 * q : 0;
-        const float cx = __shfl(chan, l0), cy = __shfl(chan, l0 + 1), cz = __shfl(chan, l0 + 2);
-        if (inside && ch == 0) {
-            K.accum[pix] = make_float4(cx, cy, cz, alpha + (float)spp);
-            K.ior[pix] = 1.0f;
-        }
-        if (COUNT) {
-            const unsigned long long im = rz_ballot(inside && ch == 0);
-            if (lane == 0 && im) atomicAdd(&K.counters->pixels, (unsigned long long)__popcll(im));
-        }
-    }
+    if (!claimDeferred) claim_ordered_sums<COUNT>(K, M, ci, addBase, nPix, ppw, nBatches);
     if (COUNT) {
         unsigned v[9] = {c.samples, c.traversals, c.tlas_nodes, c.tlas_leaf_indices, c.instances, c.blas_nodes,
                          c.triangles, c.materials, c.light_fetches};
@@ -815,6 +819,113 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
     __syncthreads();        // the next claim overwrites the scratch
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The pool a resident wave keeps ACROSS its claims (large opaque launches).
+// A claim parks a few dozen paths; lanes can only refill from a list that is much longer than the wave is wide
+// (rz_trace.h: pool_trace).  So a wave no longer works a claim's parked paths off before its next claim: they collect in the
+// wave's own pool -- third, fourth ... segments side by side, a path carries its bounce -- the claims that wait for them
+// leave their addends in K.daddends, and when the pool holds K.wpoolChunk paths (and when the claims have run out) the wave
+// traces ALL of them together, shades them 64 at a time (the late part of the shader's bounce loop, FS:705-711 / 720-769:
+// sky and the end, or scatter and Russian roulette), writes the sky term of the paths that end to their samples' slots and
+// keeps the survivors, compacted in place (ballot + prefix popcount), for the next time.  rz_deferred_sums then replays
+// the ordered sums of the claims that waited.  Late work and coherent work so run side by side on a CU all through the
+// launch -- the late rays keep the texture-address unit busy (64 B per lane and step whatever the ray), the coherent ones
+// the issue slots -- and no queue is shared between waves: nothing to synchronise, nothing to wait for.
+// A path's arithmetic does not depend on the lane, wave or moment that runs it: same bits as every other launch shape.
+template <bool COUNT, bool OVF>
+__device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restrict__ W, const size_t WS, const int n, const BlasStackT<OVF>& bstk) {
+    using namespace poolf;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    Tally c = {};
+#ifdef RZ_PROF
+    const unsigned long long tl0_ = __builtin_amdgcn_s_memtime();
+#endif
+    pool_trace<COUNT, OVF>(K, W, WS, n, bstk, c);
+#ifdef RZ_PROF
+    const unsigned long long tl1_ = __builtin_amdgcn_s_memtime();
+    c.t[12] += tl1_ - tl0_;
+    c.t[10] += 1;                                   // pools traced
+    c.t[11] += (unsigned long long)n;               // queries in them
+#endif
+    int write = 0;                                  // survivors so far: the write cursor trails the read cursor
+    for (int sb = 0; sb < n; sb += 64) {
+        const int sl = sb + lane;
+        Path P;
+        P.mode = MODE_DONE;
+        P.addLight = mk3(0.0f, 0.0f, 0.0f);
+        P.addSky = mk3(0.0f, 0.0f, 0.0f);
+        P.usedIor = 0;
+        P.ior = 1.0f;
+        unsigned back = 0, dci = 0;
+        if (sl < n) {
+            P.o = mk3(__uint_as_float(W[OX * WS + sl]), __uint_as_float(W[OY * WS + sl]), __uint_as_float(W[OZ * WS + sl]));
+            P.d = mk3(__uint_as_float(W[DX * WS + sl]), __uint_as_float(W[DY * WS + sl]), __uint_as_float(W[DZ * WS + sl]));
+            P.throughput = mk3(__uint_as_float(W[TPX * WS + sl]), __uint_as_float(W[TPY * WS + sl]), __uint_as_float(W[TPZ * WS + sl]));
+            P.seed.x = __uint_as_float(W[SEEDX * WS + sl]);
+            P.seed.y = __uint_as_float(W[SEEDY * WS + sl]);
+            P.samp = (int)W[SAMP * WS + sl];
+            back = W[BACK * WS + sl];
+            dci = W[(size_t)(RZ_GPOOL_FIELDS - 1) * WS + sl];
+            P.bounce = (int)(back >> 16);
+            P.color = mk3(0.0f, 0.0f, 0.0f);
+            P.mode = MODE_SEGMENT;
+            const int qTri = (int)W[QTRI * WS + sl];
+            const bool found = qTri >= 0;
+            HitRec h;
+            if (found) {     // the winner's point, normal and material, as at the end of trace_closest (FS:411-412, 489-491)
+                const int qInst = (int)W[QINST * WS + sl];
+                const float4 nm = *reinterpret_cast<const float4*>(K.triN + qTri);
+                h.t = __uint_as_float(W[QT * WS + sl]);
+                h.p = mk3(__uint_as_float(W[QPX * WS + sl]), __uint_as_float(W[QPY * WS + sl]), __uint_as_float(W[QPZ * WS + sl]));
+                h.n = normalize(x34_normal(K.instances[qInst].inv, mk3(nm.x, nm.y, nm.z)));
+                h.mat = __float_as_int(nm.w);
+                h.inst = qInst;
+            }
+            advance<COUNT, false>(K, P, found, h, c);      // one segment: sky and the end, or scatter (no shadow queries after bounce 0)
+        }
+        const bool parked = P.mode != MODE_DONE;
+        if (sl < n && !parked) {           // the path has ended: its sky term (FS:709; zero when it ended by roulette or budget) goes to its sample's slot
+            float* const A = K.daddends + (size_t)dci * K.dClaimStride + (size_t)((back >> 6) & 1023u) * 384;
+            const unsigned bl = back & 63u;
+            A[192 + bl] = P.addSky.x; A[256 + bl] = P.addSky.y; A[320 + bl] = P.addSky.z;
+        }
+        const unsigned long long pm = rz_ballot(parked);
+        if (parked) {
+            const size_t d = (size_t)write + __popcll(pm & below);        // d <= sl: this round's slots have all been read
+            W[OX * WS + d] = __float_as_uint(P.o.x); W[OY * WS + d] = __float_as_uint(P.o.y); W[OZ * WS + d] = __float_as_uint(P.o.z);
+            W[DX * WS + d] = __float_as_uint(P.d.x); W[DY * WS + d] = __float_as_uint(P.d.y); W[DZ * WS + d] = __float_as_uint(P.d.z);
+            W[TPX * WS + d] = __float_as_uint(P.throughput.x); W[TPY * WS + d] = __float_as_uint(P.throughput.y); W[TPZ * WS + d] = __float_as_uint(P.throughput.z);
+            W[SEEDX * WS + d] = __float_as_uint(P.seed.x); W[SEEDY * WS + d] = __float_as_uint(P.seed.y);
+            W[SAMP * WS + d] = (unsigned)P.samp;
+            W[BACK * WS + d] = ((unsigned)P.bounce << 16) | (back & 0xffffu);
+            W[(size_t)(RZ_GPOOL_FIELDS - 1) * WS + d] = dci;
+        }
+        write += mask_count(pm);
+    }
+#ifdef RZ_PROF
+    c.t[9] += __builtin_amdgcn_s_memtime() - tl1_;      // the shade rounds
+#endif
+    __syncthreads();
+    if (COUNT) {
+        unsigned v[9] = {c.samples, c.traversals, c.tlas_nodes, c.tlas_leaf_indices, c.instances, c.blas_nodes,
+                         c.triangles, c.materials, c.light_fetches};
+        unsigned long long* g = reinterpret_cast<unsigned long long*>(K.counters);
+        for (int k = 0; k < 9; ++k) {
+            unsigned x = v[k];
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+            if (lane == 0 && x) atomicAdd(&g[k], (unsigned long long)x);
+        }
+#ifdef RZ_PROF
+        unsigned long long* pr = reinterpret_cast<unsigned long long*>(K.counters + 1);
+        for (int k = 0; k < 16; ++k) if (c.p[k]) atomicAdd(&pr[k], (unsigned long long)c.p[k]);
+        if (lane == 0) { for (int k = 9; k < 12; ++k) atomicAdd(&pr[19 + k], c.t[k]); for (int k = 12; k < 16; ++k) atomicAdd(&pr[108 + k], c.t[k]); }
+        rz_prof_rounds(c, pr);
+#endif
+    }
+    return write;
+}
+
 template <bool COUNT, bool GLASS, bool OVF, int COMPACT>      // COMPACT: 0, or the units of a compacting claim (8 / 16)
 __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES_MIN_WAVES) void rz_render_samples(const KParams K, const unsigned nGroups, const unsigned perClaim,
                                                                                                                   const unsigned nClaims, const unsigned runShift) {
@@ -823,11 +934,14 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
     const unsigned long long wl_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned wl_claims = 0;
 #endif
-    if (perClaim == 0) {                        // one workgroup per pixel group (small launches, spp < 64)
-        render_samples_group<COUNT, GLASS, OVF>(K, blockIdx.x, lds_raw);
-        return;
+    if constexpr (COMPACT == 0 || GLASS) {      // (a compacting launch always claims: its instantiations carry no copy of the group code)
+        if (perClaim == 0) {                    // one workgroup per pixel group (small launches, spp < 64)
+            render_samples_group<COUNT, GLASS, OVF>(K, blockIdx.x, lds_raw);
+            return;
+        }
     }
     const ClaimMap M{nGroups, perClaim, nClaims, runShift};
+    int wpN = 0;                                // paths in this wave's cross-claim pool
     for (;;) {
         unsigned ci = 0;
         if ((threadIdx.x & 63) == 0) ci = atomicAdd(K.groupCounter, 1u);
@@ -837,10 +951,28 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
         ++wl_claims;
 #endif
         if constexpr (COMPACT != 0 && !GLASS) {
-            render_claim_compact<COUNT, OVF, COMPACT>(K, M, ci, lds_raw);
+            render_claim_compact<COUNT, OVF, COMPACT>(K, M, ci, lds_raw, wpN);
+            if (K.wpool != nullptr) {
+                // the wave's cross-claim pool has filled up: trace it -- again if so many paths survive that the next claim's
+                // could not be parked behind them (every pass moves its paths one bounce on: the bound is a backstop)
+                const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + (threadIdx.x & 63),
+                                           OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + (threadIdx.x & 63) : nullptr, K.blasStackCap};
+                for (int guard = 0; wpN >= (int)K.wpoolChunk && guard <= K.maxBounces; ++guard)
+                    wpN = pool_process<COUNT, OVF>(K, K.wpool + (size_t)blockIdx.x * K.wpoolStride * RZ_GPOOL_FIELDS, K.wpoolStride, wpN, bstk);
+            }
         } else {
             const int n = M.units_of(ci);
             for (int g = 0; g < n; ++g) render_samples_group<COUNT, GLASS, OVF>(K, (unsigned)M.group(ci, g), lds_raw);
+        }
+    }
+    if constexpr (COMPACT != 0 && !GLASS) {
+        // the claims have run out: what is left in the wave's pool, generation after generation (a path survives at most
+        // maxBounces - 1 scatters: the bound is a backstop)
+        if (K.wpool != nullptr) {
+            const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + (threadIdx.x & 63),
+                                       OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + (threadIdx.x & 63) : nullptr, K.blasStackCap};
+            for (int guard = 0; wpN > 0 && guard <= K.maxBounces; ++guard)
+                wpN = pool_process<COUNT, OVF>(K, K.wpool + (size_t)blockIdx.x * K.wpoolStride * RZ_GPOOL_FIELDS, K.wpoolStride, wpN, bstk);
         }
     }
 #ifdef RZ_PROF
@@ -850,6 +982,19 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
         rz_wave_log[blockIdx.x][2] = wl_claims;
     }
 #endif
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(64) void rz_deferred_sums(const KParams K, const unsigned nGroups, const unsigned perClaim, const unsigned nClaims, const unsigned runShift) {
+    const ClaimMap M{nGroups, perClaim, nClaims, runShift};
+    const int spp = K.spp;
+    const int nBatches = (spp + 63) / 64;
+    const int ppw = spp >= 64 ? 1 : 64 / spp;
+    for (unsigned ci = blockIdx.x; ci < nClaims; ci += gridDim.x) {
+        if (sload1(K.dflags + ci) == 0) continue;
+        const int nPix = M.units_of(ci) * ppw;
+        claim_ordered_sums<COUNT>(K, M, ci, K.daddends + (size_t)ci * K.dClaimStride, nPix, ppw, nBatches);
+    }
 }
 
 // FS:772-773 + 8-bit quantisation: rgba8 = round(clamp(sum / n, 0, 1) * 255), a = 255.
@@ -966,6 +1111,11 @@ SamplesPlan plan_render_samples(int spp, int nSlots, bool glass) {
     const long long claims = p.perClaim ? (p.groups + p.perClaim - 1) / p.perClaim : p.groups;
     p.grid = p.perClaim ? std::min<long long>(claims, (long long)nCU * RZ_PERSIST_WAVES_PER_CU) : p.groups;
     p.nClaims = p.perClaim ? claims : 0;
+    // The waves of a large compacting launch keep their pool of parked paths ACROSS claims (pool_process): a claim's own pool
+    // holds a few dozen paths, and lanes can only refill from a list much longer than the wave is wide.
+    // RZ_CROSS_CLAIM_POOL=0/1 overrides (A/B aid).
+    p.crossClaimPool = p.compact && units >= RZ_CROSS_POOL_MIN_UNITS;
+    if (const char* e = std::getenv("RZ_CROSS_CLAIM_POOL")) p.crossClaimPool = p.compact && std::atoi(e) != 0;
     // the shape of a claim (ClaimMap): one run of consecutive groups at 64 spp and more (a tile row; its parked paths are
     // neighbours), runs of RZ_CLAIM_RUN_SMALL_SPP groups from as many bands of the frame as it takes below (a claim of
     // consecutive 4-pixel groups inside a mesh costs many times the average claim, and the launch waits for the last one)
@@ -1007,6 +1157,12 @@ void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream
         else { if (ovf) RZ_LAUNCH_SAMPLES(false, false, true, 0); else RZ_LAUNCH_SAMPLES(false, false, false, 0); }
     }
 #undef RZ_LAUNCH_SAMPLES
+    if (compact && K.wpool != nullptr) {
+        // the ordered sums of the claims that waited for parked paths -- same stream, right behind the render kernel
+        const dim3 gs((unsigned)std::min<long long>(plan.nClaims, grid * 4));
+        if (counted) hipLaunchKernelGGL((rz_deferred_sums<true>), gs, b, 0, stream, K, nGroups, (unsigned)perClaim, (unsigned)plan.nClaims, (unsigned)plan.runShift);
+        else hipLaunchKernelGGL((rz_deferred_sums<false>), gs, b, 0, stream, K, nGroups, (unsigned)perClaim, (unsigned)plan.nClaims, (unsigned)plan.runShift);
+    }
 }
 
 // The local hemisphere direction of a zero seed (rz_path.h: random_hemisphere_direction), by the kernels' own arithmetic.

@@ -126,6 +126,14 @@ struct KParams {
     float hemi0[3];         // rz_path.h: hemisphere_local((+0, +0)), the local direction of every bounce-0 scatter (rz_hemi0_kernel, once per context)
     int32_t traceRoundCap;  // rz_trace.h: trace_spread's backstop -- more rounds than any walk of this TLAS takes (a lane enters an instance at most once per leaf entry)
     int32_t spreadTrace;    // 1: third and later path segments are traced lane by lane (rz_trace.h: trace_spread); 0: always the wave-cursor walk (a scheduling choice: same image)
+    // ---- the pool of parked paths a resident wave keeps ACROSS its claims (rz_kernels.hip: pool_process; null: every claim works
+    //      its own pool off before the next one, as small launches do)
+    unsigned* wpool;        // [resident wave][RZ_GPOOL_FIELDS][wpoolStride]
+    uint32_t wpoolStride;   // slots per field: wpoolChunk + the most one claim can park
+    uint32_t wpoolChunk;    // the wave traces its pool when it holds at least this many paths (and at the end of the launch)
+    float* daddends;        // [claim][unit][6][64]: the addends of the claims whose pixels wait for parked paths
+    int32_t* dflags;        // [claim] 1: waiting (summed by rz_deferred_sums)
+    uint32_t dClaimStride;  // floats per claim in daddends (units of a claim x 384)
 };
 
 // Arguments of the device TLAS rebuild (rz_tlas_device.hip: rz_tlas_refit; filled in by rz_context.hip).
@@ -147,13 +155,14 @@ struct TlasWork {
 
 // How rz_render_samples is launched (rz_kernels.hip: plan_render_samples): groups of pixels, the grid, and the number
 // of groups a persistent wave claims per atomic (0: one workgroup per group).
-struct SamplesPlan { long long groups, grid; int perClaim; bool compact; int claimUnits; long long nClaims; int runShift; };   // claimUnits: 8 or 16 when compact; nClaims / runShift: rz_kernels.hip, ClaimMap
+struct SamplesPlan { long long groups, grid; int perClaim; bool compact; int claimUnits; long long nClaims; int runShift; bool crossClaimPool; };   // claimUnits: 8 or 16 when compact; nClaims / runShift: rz_kernels.hip, ClaimMap
 
 // Per resident wave of a compacting launch: the two addends of every sample of up to `units` (pixel, batch) units
 // [unit][6][64] floats, then the pool of parked paths [RZ_POOL_FIELDS][units * 64] dwords.  The kernel is instantiated for
 // claims of 8 and of 16 units (rz_kernels.hip: plan_render_samples picks by the size of the launch).
 constexpr int RZ_CLAIM_UNITS_SMALL = 8, RZ_CLAIM_UNITS_LARGE = 16;
 constexpr int RZ_POOL_FIELDS = 23;      // the parked path (13), its query (8), the items of a B phase (2): rz_trace.h, namespace poolf
+constexpr int RZ_GPOOL_FIELDS = RZ_POOL_FIELDS + 1;     // a wave's cross-claim pool: ... + the claim a parked path belongs to (field 23)
 constexpr size_t claim_scratch_dwords(int units) { return (size_t)units * 6 * 64 + (size_t)RZ_POOL_FIELDS * units * 64; }
 
 }  // namespace rz

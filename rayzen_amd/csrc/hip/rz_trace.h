@@ -692,13 +692,19 @@ static_assert(poolf::ITINST + 1 == RZ_POOL_FIELDS, "pool fields");
 #ifndef RZ_REFILL_MIN_LANES
 #define RZ_REFILL_MIN_LANES 8      // idle lanes it takes to interrupt the walk for a refill (unless nobody walks at all)
 #endif
+#ifndef RZ_TAIL_LANES
+#define RZ_TAIL_LANES 16           // a B phase whose list has run out ends when fewer lanes than this still walk (they go on in the next one)
+#endif
 
-template <bool COUNT, bool OVF, int PS>
-__device__ __forceinline__ void pool_trace(const KParams& K, unsigned* __restrict__ pool, const int nQ, const BlasStackT<OVF>& bstk, Tally& c) {
+// pool: field f of slot s is pool[f * PS + s] (PS: the wave's own pool in the claim scratch, or the capacity of the launch's
+// global pool when a chunk of it is traced in place).
+template <bool COUNT, bool OVF>
+__device__ __forceinline__ void pool_trace(const KParams& K, unsigned* __restrict__ pool, const size_t PS, const int nQ, const BlasStackT<OVF>& bstk, Tally& c) {
     using namespace poolf;
     const int lane = threadIdx.x & 63;
     const int nDfs = K.nTlasDfs;
     const unsigned long long below = (1ull << lane) - 1ull;
+    constexpr unsigned BUSY = 0x80000000u;      // in QIDX: an item of this query is being walked (the T phase leaves the query alone)
     for (int s = lane; s < nQ; s += 64) {
         pool[QT * PS + s] = __float_as_uint(1e30f);
         pool[QTRI * PS + s] = 0xffffffffu;
@@ -707,10 +713,19 @@ __device__ __forceinline__ void pool_trace(const KParams& K, unsigned* __restric
     }
     if (COUNT) for (int s = lane; s < nQ; s += 64) c.traversals += 1;
     __syncthreads();
-    // (every iteration enters each unfinished query into one more instance, and a query enters at most K.traceRoundCap:
-    //  the bound is a backstop -- a wave that never leaves this loop takes the device with it)
-    for (int iter = 0; iter < K.traceRoundCap; ++iter) {
-        // ---- T phase
+    // the walk a lane is in lives across the phases: a B phase ends when its list has run out and only a few long walks are
+    // left -- those go on in the next B phase, beside the items the T phase has made in the meantime, instead of keeping
+    // sixty lanes waiting for them (measured with a B phase that ran to its last walk: chunks of 512 queries walked 8 lanes wide)
+    int slot = -1, inst = 0;                    // the item this lane holds (slot < 0: none)
+    int cur = -1, sp = 0, best = -1, pbase = 0, tbase = 0;
+    float tLoc = 1e30f;
+    v3 lo = mk3(0.0f, 0.0f, 0.0f), ld = mk3(1.0f, 1.0f, 1.0f);
+    RayPk RP = make_raypk(lo, ld);
+    // (every iteration retires at least one item or finishes: a query enters at most K.traceRoundCap instances and there are
+    //  nQ of them -- the bound is a backstop; a wave that never leaves this loop takes the device with it)
+    const long long maxIter = (long long)K.traceRoundCap * (nQ > 0 ? nQ : 1) + 8;
+    for (long long iter = 0; iter < maxIter; ++iter) {
+        // ---- T phase: every query that is neither finished nor being walked moves on to the next leaf its ray passes
 #ifdef RZ_PROF
         const unsigned long long tT0_ = __builtin_amdgcn_s_memtime();
         c.rnd = 7;      // (the per-round site counters of the diagnostic build: everything pool_trace does is filed under round 7)
@@ -718,7 +733,9 @@ __device__ __forceinline__ void pool_trace(const KParams& K, unsigned* __restric
         int nItems = 0;
         for (int sb = 0; sb < nQ; sb += 64) {
             const int s = sb + lane;
-            int idx = s < nQ ? (int)pool[QIDX * PS + s] : nDfs;
+            const unsigned raw = s < nQ ? pool[QIDX * PS + s] : (unsigned)nDfs;
+            const bool mine = s < nQ && (raw & BUSY) == 0u;
+            int idx = mine ? (int)raw : nDfs;
             unsigned long long wm = rz_ballot(idx < nDfs);
             if (wm == 0ull) continue;
             int sub = 0, pinst = -1;
@@ -758,7 +775,7 @@ __device__ __forceinline__ void pool_trace(const KParams& K, unsigned* __restric
                 }
                 wm = (++steps <= nDfs) ? rz_ballot(pinst < 0 && idx < nDfs) : 0ull;     // (a lane's position strictly grows: at most nDfs steps)
             }
-            if (s < nQ) { pool[QIDX * PS + s] = (unsigned)idx; pool[QSUB * PS + s] = (unsigned)sub; }
+            if (mine) { pool[QIDX * PS + s] = (unsigned)idx | (pinst >= 0 ? BUSY : 0u); pool[QSUB * PS + s] = (unsigned)sub; }
             const unsigned long long hm = rz_ballot(pinst >= 0);
             if (pinst >= 0) {
                 const int k = nItems + __popcll(hm & below);
@@ -771,15 +788,11 @@ __device__ __forceinline__ void pool_trace(const KParams& K, unsigned* __restric
         const unsigned long long tB0_ = __builtin_amdgcn_s_memtime();
         c.t[13] += tB0_ - tT0_;
 #endif
-        if (nItems == 0) break;
+        if (nItems == 0 && rz_ballot(slot >= 0) == 0ull) break;      // no query has anywhere to go and nobody walks: the pool is traced
         __syncthreads();
         // ---- B phase: walk the items, lanes refilling from the list
         int next = 0;                               // wave-uniform: the next item to hand out
-        int slot = -1, inst = 0;                    // the item this lane holds (slot < 0: none)
-        int cur = -1, sp = 0, best = -1, pbase = 0, tbase = 0;
-        float tLoc = 1e30f;
-        v3 lo = mk3(0.0f, 0.0f, 0.0f), ld = mk3(1.0f, 1.0f, 1.0f);
-        RayPk RP = make_raypk(lo, ld);
+        int retired = 0;                            // items retired in this phase
         // (an item is walked in fewer than 2 x its BLAS's nodes rounds -- the host has checked that the node arrays are trees --
         //  and every refill hands out or retires an item: the bound is a backstop)
         bool again;
@@ -788,8 +801,10 @@ __device__ __forceinline__ void pool_trace(const KParams& K, unsigned* __restric
             // -- refill: idle lanes retire the item they hold and take the next one
             bool idle = cur == -1 && sp == 0;
             unsigned long long im = rz_ballot(idle);
-            bool refill = (next < nItems || rz_ballot(idle && slot >= 0) != 0ull) &&
-                          (mask_count(im) >= RZ_REFILL_MIN_LANES || rz_ballot(!idle) == 0ull);
+            const int walkers = mask_count(rz_ballot(!idle));
+            // (when the list has run out the phase is about to end -- see below -- and the finished items are retired on the way out)
+            bool refill = (next < nItems && (mask_count(im) >= RZ_REFILL_MIN_LANES || walkers == 0)) ||
+                          (next >= nItems && rz_ballot(idle && slot >= 0) != 0ull && (walkers < RZ_TAIL_LANES || mask_count(im) >= RZ_REFILL_MIN_LANES));
 #ifdef RZ_PROF
             const unsigned long long tR0_ = __builtin_amdgcn_s_memtime();
             RZ_SITE(c, 0);              // rounds of the B phase and the lanes in them
@@ -797,21 +812,25 @@ __device__ __forceinline__ void pool_trace(const KParams& K, unsigned* __restric
 #endif
             while (refill) {
                 const int pending = nItems - next;
+                retired += mask_count(rz_ballot(idle && slot >= 0));       // (wave-uniform: counted outside the lanes' branch)
                 if (idle) {
-                    if (slot >= 0 && best >= 0) {       // FS:410, 484-486: the hit in world space, kept if strictly nearer
-                        const float4* __restrict__ I4 = reinterpret_cast<const float4*>(K.instances + inst);
-                        const float4 b0 = I4[3], b1 = I4[4], b2 = I4[5];
-                        const float mf[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
-                        const v3 o = mk3(__uint_as_float(pool[OX * PS + slot]), __uint_as_float(pool[OY * PS + slot]), __uint_as_float(pool[OZ * PS + slot]));
-                        const v3 localHit = lo + ld * tLoc;
-                        const v3 worldHit = x34_point(mf, localHit);
-                        const float tWorld = length(worldHit - o);
-                        if (tWorld < __uint_as_float(pool[QT * PS + slot])) {
-                            pool[QT * PS + slot] = __float_as_uint(tWorld);
-                            pool[QPX * PS + slot] = __float_as_uint(worldHit.x); pool[QPY * PS + slot] = __float_as_uint(worldHit.y); pool[QPZ * PS + slot] = __float_as_uint(worldHit.z);
-                            pool[QTRI * PS + slot] = (unsigned)best;
-                            pool[QINST * PS + slot] = (unsigned)inst;
+                    if (slot >= 0) {
+                        if (best >= 0) {       // FS:410, 484-486: the hit in world space, kept if strictly nearer
+                            const float4* __restrict__ I4 = reinterpret_cast<const float4*>(K.instances + inst);
+                            const float4 b0 = I4[3], b1 = I4[4], b2 = I4[5];
+                            const float mf[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+                            const v3 o = mk3(__uint_as_float(pool[OX * PS + slot]), __uint_as_float(pool[OY * PS + slot]), __uint_as_float(pool[OZ * PS + slot]));
+                            const v3 localHit = lo + ld * tLoc;
+                            const v3 worldHit = x34_point(mf, localHit);
+                            const float tWorld = length(worldHit - o);
+                            if (tWorld < __uint_as_float(pool[QT * PS + slot])) {
+                                pool[QT * PS + slot] = __float_as_uint(tWorld);
+                                pool[QPX * PS + slot] = __float_as_uint(worldHit.x); pool[QPY * PS + slot] = __float_as_uint(worldHit.y); pool[QPZ * PS + slot] = __float_as_uint(worldHit.z);
+                                pool[QTRI * PS + slot] = (unsigned)best;
+                                pool[QINST * PS + slot] = (unsigned)inst;
+                            }
                         }
+                        pool[QIDX * PS + slot] &= ~BUSY;        // the T phase may move this query on
                     }
                     slot = -1;
                     const int rank = __popcll(im & below);
@@ -877,8 +896,8 @@ __device__ __forceinline__ void pool_trace(const KParams& K, unsigned* __restric
                 more = mask_count(actMask) >= RZ_DESCEND_MIN_LANES;
             }
             // -- leaves
-            again = rz_ballot((cur != -1) || (sp > 0)) != 0ull;
-            if (again) {
+            const unsigned long long alive = rz_ballot((cur != -1) || (sp > 0));
+            if (alive != 0ull) {
                 const bool leaf = cur < 0;
                 const int v = ~cur;
                 const int first = (v >> 4) + tbase, count = leaf ? (v & 15) : 0;
@@ -904,8 +923,13 @@ __device__ __forceinline__ void pool_trace(const KParams& K, unsigned* __restric
                     if (!pop_entry(bstk, sp, tLoc, cur)) cur = -1;
                 }
             }
-            // (nobody walks: go on while items remain or a lane still holds a finished one)
-            again = again || next < nItems || rz_ballot(slot >= 0) != 0ull;
+            // The phase goes on while its list lasts, and after that while many lanes still walk; it ends -- once something has
+            // been retired, so that the next T phase has a query to move -- when at most RZ_TAIL_LANES long walks are left: they
+            // continue in the next B phase.  Lanes that hold a finished item have retired it above by then (refill's second case).
+            const int stillWalking = mask_count(rz_ballot((cur != -1) || (sp > 0)));
+            const bool holding = rz_ballot(slot >= 0 && cur == -1 && sp == 0) != 0ull;
+            again = next < nItems || stillWalking >= RZ_TAIL_LANES || holding || (stillWalking > 0 && retired == 0);
+            // (holding: one more round, whose refill retires the finished items before the T phase looks at their queries)
         } while (again && ++guard < (1u << 28));
 #ifdef RZ_PROF
         c.t[14] += __builtin_amdgcn_s_memtime() - tB0_;

@@ -165,63 +165,62 @@ void BVH::buildBLAS(const Triangle* tris, int n) {
     }
 }
 
+// BVH::buildTLAS (RayZen/src/BVH.cpp:178-240): midpoint split on the longest axis of the instances' world boxes, ONE instance
+// per leaf.  The output -- node numbering included -- is a function of the instance ranges alone, which is how it is built
+// here (and, level by level, on the device: rz_tlas_device.hip):
+//   * a range of c instances becomes a subtree of exactly 2c - 1 nodes;
+//   * the reference appends a node's two children as a pair when it visits the node, and visits in depth-first order, left
+//     subtree first: the k-th INTERNAL node it visits (k from 0, the root) therefore owns nodes 2k + 1 and 2k + 2; the left
+//     child of internal node k is internal node k + 1 (if it has more than one instance), the right child internal node
+//     k + (instances on the left) -- a left subtree over m instances holds m - 1 internal nodes;
+//   * leaves are reached left to right, so the leaf over position p of the (partitioned) order is the p-th one written to
+//     the index array: leftFirst = p, and the index array IS the final order.
+// So the nodes live in an array sized up front, each range writes its own node and names its children by arithmetic, and
+// the ranges may be worked off in any order (a plain work list here).  Per node the arithmetic is the reference's: the
+// box folded over the range in order (glm::min / glm::max keep the first of equals, so a zero keeps its sign), the split
+// plane at the middle of the longest extent (x on ties, as BVH.cpp:196-198), the centre test `c < split` and the swap
+// partition of BVH.cpp:201-209 -- its exact permutation is part of the output -- and the fall-back split in the middle.
 void BVH::buildTLAS(const std::vector<BVHInstance>& meshInstances, const std::vector<BVHNode>& meshRootNodes) {
     const float FMAX = std::numeric_limits<float>::max();
-    triIndices.clear();
-    nodes.clear();
     instances = meshInstances;
-    int numMeshes = (int)meshInstances.size();
-    std::vector<int> meshIndices(numMeshes);
-    std::iota(meshIndices.begin(), meshIndices.end(), 0);
-    std::vector<BuildEntry> stack;
-    stack.push_back({0, 0, numMeshes});
-    nodes.push_back(BVHNode{});
-    while (!stack.empty()) {
-        BuildEntry e = stack.back();
-        stack.pop_back();
-        int start = e.start, end = e.end, count = end - start;
-        vec3 bmin(FMAX), bmax(-FMAX);
-        for (int i = start; i < end; ++i) {
-            const BVHNode& r = meshRootNodes[meshIndices[i]];
-            bmin = vmin(bmin, r.boundsMin);
-            bmax = vmax(bmax, r.boundsMax);
+    const int n = (int)meshInstances.size();
+    triIndices.resize((size_t)n);
+    std::iota(triIndices.begin(), triIndices.end(), 0);         // the order being partitioned; final = the index array
+    nodes.assign((size_t)std::max(1, 2 * n - 1), BVHNode{});
+    if (n <= 0) {           // empty scene (the reference would not terminate): an empty root with the fold's identity box
+        nodes[0].boundsMin = vec3(FMAX); nodes[0].boundsMax = vec3(-FMAX);
+        nodes[0].leftFirst = 0; nodes[0].count = 0;
+        return;
+    }
+    struct Range { int node, internalRank, first, last; };      // instances [first, last) of the order
+    std::vector<Range> work{{0, 0, 0, n}};
+    while (!work.empty()) {
+        const Range r = work.back();
+        work.pop_back();
+        BVHNode& N = nodes[(size_t)r.node];
+        vec3 lo(FMAX), hi(-FMAX);
+        for (int p = r.first; p < r.last; ++p) {
+            const BVHNode& box = meshRootNodes[(size_t)triIndices[(size_t)p]];
+            lo = vmin(lo, box.boundsMin);
+            hi = vmax(hi, box.boundsMax);
         }
-        nodes[e.nodeIdx].boundsMin = bmin;
-        nodes[e.nodeIdx].boundsMax = bmax;
-        if (count == 1) {
-            nodes[e.nodeIdx].leftFirst = (int)triIndices.size();
-            nodes[e.nodeIdx].count = 1;
-            triIndices.push_back(meshIndices[start]);
-            continue;
+        N.boundsMin = lo;
+        N.boundsMax = hi;
+        const int members = r.last - r.first;
+        if (members == 1) { N.leftFirst = r.first; N.count = 1; continue; }
+        const vec3 size = hi - lo;
+        const int axis = (size.y > size.x && size.y > size.z) ? 1 : (size.z > size.x ? 2 : 0);
+        const float plane = 0.5f * (lo[axis] + hi[axis]);
+        int cut = r.first;                                      // BVH.cpp:201-209: the instances whose centre lies below the plane, swapped to the front
+        for (int p = r.first; p < r.last; ++p) {
+            const BVHNode& box = meshRootNodes[(size_t)triIndices[(size_t)p]];
+            if ((box.boundsMin[axis] + box.boundsMax[axis]) * 0.5f < plane) std::swap(triIndices[(size_t)p], triIndices[(size_t)cut++]);
         }
-        if (count <= 0) {   // empty scene (the reference would not terminate): an empty root
-            nodes[e.nodeIdx].leftFirst = 0;
-            nodes[e.nodeIdx].count = 0;
-            continue;
-        }
-        vec3 extent = bmax - bmin;
-        int axis = 0;
-        if (extent.y > extent.x && extent.y > extent.z) axis = 1;
-        else if (extent.z > extent.x) axis = 2;
-        float split = 0.5f * (bmin[axis] + bmax[axis]);
-        int mid = start;
-        for (int i = start; i < end; ++i) {
-            const BVHNode& r = meshRootNodes[meshIndices[i]];
-            float c = (r.boundsMin[axis] + r.boundsMax[axis]) * 0.5f;
-            if (c < split) {
-                std::swap(meshIndices[i], meshIndices[mid]);
-                ++mid;
-            }
-        }
-        if (mid == start || mid == end) mid = start + (count / 2);
-        int leftIdx = (int)nodes.size();
-        int rightIdx = leftIdx + 1;
-        nodes[e.nodeIdx].leftFirst = leftIdx;
-        nodes[e.nodeIdx].count = -1;
-        nodes.push_back(BVHNode{});
-        nodes.push_back(BVHNode{});
-        stack.push_back({rightIdx, mid, end});
-        stack.push_back({leftIdx, start, mid});
+        if (cut == r.first || cut == r.last) cut = r.first + members / 2;
+        N.leftFirst = 2 * r.internalRank + 1;
+        N.count = -1;
+        work.push_back({N.leftFirst, r.internalRank + 1, r.first, cut});
+        work.push_back({N.leftFirst + 1, r.internalRank + (cut - r.first), cut, r.last});
     }
 }
 
@@ -240,32 +239,6 @@ int BVH::depth() const {
         }
     }
     return best;
-}
-
-bool BVH::saveToFile(const std::string& filename) const {
-    std::ofstream out(filename, std::ios::binary);
-    if (!out) return false;
-    size_t nodeCount = nodes.size(), triIdxCount = triIndices.size();
-    out.write(reinterpret_cast<const char*>(&nodeCount), sizeof(size_t));
-    out.write(reinterpret_cast<const char*>(nodes.data()), (std::streamsize)(nodeCount * sizeof(BVHNode)));
-    out.write(reinterpret_cast<const char*>(&triIdxCount), sizeof(size_t));
-    out.write(reinterpret_cast<const char*>(triIndices.data()), (std::streamsize)(triIdxCount * sizeof(int)));
-    return out.good();
-}
-
-bool BVH::loadFromFile(const std::string& filename) {
-    std::ifstream in(filename, std::ios::binary);
-    if (!in) return false;
-    size_t nodeCount = 0, triIdxCount = 0;
-    in.read(reinterpret_cast<char*>(&nodeCount), sizeof(size_t));
-    if (!in || nodeCount > (size_t)1 << 31) return false;
-    nodes.resize(nodeCount);
-    in.read(reinterpret_cast<char*>(nodes.data()), (std::streamsize)(nodeCount * sizeof(BVHNode)));
-    in.read(reinterpret_cast<char*>(&triIdxCount), sizeof(size_t));
-    if (!in || triIdxCount > (size_t)1 << 31) return false;
-    triIndices.resize(triIdxCount);
-    in.read(reinterpret_cast<char*>(triIndices.data()), (std::streamsize)(triIdxCount * sizeof(int)));
-    return in.good();
 }
 
 }  // namespace rayzen

@@ -73,8 +73,6 @@ public:
     // library sizes its LDS traversal stacks from this.
     int depth() const;
     // BVH.cpp:242-265: size_t count + raw POD, nodes then triIndices.
-    bool saveToFile(const std::string& filename) const;
-    bool loadFromFile(const std::string& filename);
 };
 
 struct Material {

@@ -2,6 +2,7 @@
 #include "SceneCache.h"
 
 #include <algorithm>
+#include <map>
 #include <sys/stat.h>
 #include <sys/types.h>
 
@@ -12,18 +13,22 @@ std::string join(const std::string& dir, const char* name) {
     if (dir.empty()) return name;
     return dir.back() == '/' ? dir + name : dir + "/" + name;
 }
-int subtreeDepth(const std::vector<BVHNode>& nodes, int root) {
-    if (root < 0 || root >= (int)nodes.size()) return 0;
+// Depth of the tree whose root is nodes[base] and whose child indices are relative to `base` (a BLAS inside the
+// concatenated array, or the TLAS with base 0): walked in place.
+int subtreeDepth(const std::vector<BVHNode>& nodes, size_t base) {
+    if (base >= nodes.size()) return 0;
+    const size_t span = nodes.size() - base;
     int best = 1;
-    std::vector<std::pair<int, int>> st{{root, 1}};
+    std::vector<std::pair<int, int>> st{{0, 1}};
     size_t guard = 0;
-    while (!st.empty() && guard++ <= nodes.size() * 2) {
+    while (!st.empty() && guard++ <= span * 2) {
         auto [n, d] = st.back();
         st.pop_back();
         best = std::max(best, d);
-        if (nodes[n].count < 0 && nodes[n].leftFirst >= 0 && nodes[n].leftFirst + 1 < (int)nodes.size()) {
-            st.push_back({nodes[n].leftFirst, d + 1});
-            st.push_back({nodes[n].leftFirst + 1, d + 1});
+        const BVHNode& N = nodes[base + (size_t)n];
+        if (N.count < 0 && N.leftFirst >= 0 && (size_t)N.leftFirst + 1 < span) {
+            st.push_back({N.leftFirst, d + 1});
+            st.push_back({N.leftFirst + 1, d + 1});
         }
     }
     return best;
@@ -50,14 +55,16 @@ bool loadSceneCache(const std::string& dir, SceneBuffers& b) {
         return false;
     t.blasRoots.clear();
     t.maxBLASDepth = 1;
+    std::map<int, int> depthOf;
     for (const BVHInstance& inst : t.meshInstances) {
         if (inst.blasNodeOffset < 0 || inst.blasNodeOffset >= (int)t.allBLASNodes.size()) return false;
         t.blasRoots.push_back(t.allBLASNodes[(size_t)inst.blasNodeOffset]);
-        // depth of this instance's BLAS: walk it with node indices relative to its offset
-        std::vector<BVHNode> sub(t.allBLASNodes.begin() + inst.blasNodeOffset, t.allBLASNodes.end());
-        t.maxBLASDepth = std::max(t.maxBLASDepth, subtreeDepth(sub, 0));
+        // depth of this instance's BLAS, once per distinct BLAS (instances of one mesh share an offset)
+        auto seen = depthOf.find(inst.blasNodeOffset);
+        if (seen == depthOf.end()) seen = depthOf.emplace(inst.blasNodeOffset, subtreeDepth(t.allBLASNodes, (size_t)inst.blasNodeOffset)).first;
+        t.maxBLASDepth = std::max(t.maxBLASDepth, seen->second);
     }
-    t.tlasDepth = std::max(1, subtreeDepth(t.tlasNodes, 0));
+    t.tlasDepth = std::max(1, subtreeDepth(t.tlasNodes, (size_t)0));
     b = std::move(t);
     return true;
 }
@@ -86,13 +93,15 @@ void makeDirs(const std::string& dir) {          // fs::create_directories
 void finishDerived(SceneBuffers& b) {            // what the renderer wants besides the six arrays
     b.blasRoots.clear();
     b.maxBLASDepth = 1;
+    std::map<int, int> depthOf;
     for (const BVHInstance& inst : b.meshInstances) {
         if (inst.blasNodeOffset < 0 || inst.blasNodeOffset >= (int)b.allBLASNodes.size()) { b.blasRoots.push_back(BVHNode{}); continue; }
         b.blasRoots.push_back(b.allBLASNodes[(size_t)inst.blasNodeOffset]);
-        std::vector<BVHNode> sub(b.allBLASNodes.begin() + inst.blasNodeOffset, b.allBLASNodes.end());
-        b.maxBLASDepth = std::max(b.maxBLASDepth, subtreeDepth(sub, 0));
+        auto seen = depthOf.find(inst.blasNodeOffset);
+        if (seen == depthOf.end()) seen = depthOf.emplace(inst.blasNodeOffset, subtreeDepth(b.allBLASNodes, (size_t)inst.blasNodeOffset)).first;
+        b.maxBLASDepth = std::max(b.maxBLASDepth, seen->second);
     }
-    b.tlasDepth = std::max(1, subtreeDepth(b.tlasNodes, 0));
+    b.tlasDepth = std::max(1, subtreeDepth(b.tlasNodes, (size_t)0));
 }
 }  // namespace
 

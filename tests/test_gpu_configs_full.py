@@ -115,7 +115,7 @@ def test_c5_full_size_one_million_triangles_4k_at_its_stated_128_spp():
     r = Renderer(0)
     sc = _c5_scene(r, W, H)
     gpu = hip_render(sc, W, H, spp, b, renderer=r)
-    assert r.last_kernel_name() == "rz_render_samples"
+    assert r.last_kernel_name() in ("rz_render_samples", "rz_render_samples+pool")
     plan = r.debug_last_plan()
     r.close()
     assert plan["batches_per_pixel"] == 2 and plan["pixels_per_wave"] == 1
@@ -301,3 +301,77 @@ def test_compacting_launch_below_64_spp_continued_frames_tile_ranks_and_counters
     _, rc = rzo.render(osc, fr, accum=ref, nthreads=16, want_counters=True)
     assert cnt == rc
     assert (img.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+# ---- the pool a wave keeps ACROSS its claims (round 3: pool_process / pool_trace / rz_deferred_sums) -------------------------
+
+@pytest.mark.parametrize("W,H,spp,claim,chunk", [(640, 512, 64, 8, None), (643, 509, 100, 4, None), (640, 512, 16, 8, None), (323, 253, 5, 3, None),
+                                                 (640, 512, 128, 8, 3000), (640, 512, 16, 16, 777), (640, 512, 64, 8, 64), (640, 512, 64, 8, 1)])
+def test_cross_claim_pool_equals_the_per_claim_pools_and_the_oracle(W, H, spp, claim, chunk, monkeypatch):
+    """The waves of a large opaque launch do not work a claim's parked paths off before the next claim: they collect in the
+    wave's own pool, third and later segments side by side, and are traced together when `chunk` of them have come together
+    (lanes refilling from the list of pending BLAS walks: pool_trace) and at the end of the launch; the claims that wait
+    leave their addends behind and rz_deferred_sums replays their ordered sums.  Forced here on small frames
+    (RZ_CROSS_CLAIM_POOL=1 + claims by RZ_GROUPS_PER_CLAIM) with chunks from 1 (every claim) to 3000 (the end of the launch
+    only), sizes that are not multiples of 64, and several pixels per wave: every shape must give the image of the per-claim
+    pools, of one workgroup per group, and of the oracle.  6 bounces: paths survive several passes of a pool.
+    Reference semantics: fragment_shader.glsl:705-711, 720-769 (the late part of the bounce loop)."""
+    from rayzen_amd.renderer import Renderer
+    sc = S.bunny_scene(n=16, aspect=W / H)
+    b = 6
+    plain = hip_render(sc, W, H, spp, b)
+    monkeypatch.setenv("RZ_GROUPS_PER_CLAIM", str(claim))
+    monkeypatch.setenv("RZ_CROSS_CLAIM_POOL", "0")
+    local = hip_render(sc, W, H, spp, b)
+    monkeypatch.setenv("RZ_CROSS_CLAIM_POOL", "1")
+    if chunk is not None:
+        monkeypatch.setenv("RZ_WPOOL_CHUNK", str(chunk))
+    r = Renderer(0)
+    cross = hip_render(sc, W, H, spp, b, renderer=r)
+    assert r.last_kernel_name() == "rz_render_samples+pool"
+    r.close()
+    for k in ("RZ_GROUPS_PER_CLAIM", "RZ_CROSS_CLAIM_POOL", "RZ_WPOOL_CHUNK"):
+        monkeypatch.delenv(k, raising=False)
+    assert (cross.view(np.uint32) == local.view(np.uint32)).all(), mismatch_report(cross, local)
+    assert (cross.view(np.uint32) == plain.view(np.uint32)).all(), mismatch_report(cross, plain)
+    assert (cross[..., 3] == spp).all()
+    _band_check(sc, W, H, spp, b, cross)
+
+
+def test_cross_claim_pool_when_every_path_survives(monkeypatch):
+    """An all-mirror scene: nothing dies before the bounce budget, so a pool that has been traced is as full as before and
+    is traced again before the next claim can park behind it (the inner loop of the claim loop)."""
+    W, H, spp, b = 640, 512, 64, 7
+    sc = S.bunny_scene(n=12, aspect=W / H, bunny_material=2, floor_material=2)
+    plain = hip_render(sc, W, H, spp, b)
+    monkeypatch.setenv("RZ_GROUPS_PER_CLAIM", "8")
+    monkeypatch.setenv("RZ_CROSS_CLAIM_POOL", "1")
+    monkeypatch.setenv("RZ_WPOOL_CHUNK", "200")
+    cross = hip_render(sc, W, H, spp, b)
+    for k in ("RZ_GROUPS_PER_CLAIM", "RZ_CROSS_CLAIM_POOL", "RZ_WPOOL_CHUNK"):
+        monkeypatch.delenv(k, raising=False)
+    assert (cross.view(np.uint32) == plain.view(np.uint32)).all(), mismatch_report(cross, plain)
+    _band_check(sc, W, H, spp, b, cross)
+
+
+def test_cross_claim_pool_continued_frames_tile_ranks_and_counters(monkeypatch):
+    sc = S.bunny_scene(n=12, aspect=1280 / 1024)
+    W, H, b = 1280, 1024, 5
+    monkeypatch.setenv("RZ_GROUPS_PER_CLAIM", "8")
+    monkeypatch.setenv("RZ_CROSS_CLAIM_POOL", "1")
+    whole = hip_render(sc, W, H, 128, b)
+    two = hip_render(sc, W, H, 128, b, chunk=64)            # sample_base = 64: the deferred sums read the accumulation buffer back
+    assert (two.view(np.uint32) == whole.view(np.uint32)).all(), mismatch_report(two, whole)
+    total = np.zeros_like(whole)
+    for k in range(3):
+        total += hip_render(sc, W, H, 128, b, tile_rank=k, tile_nranks=3)
+    assert (total.view(np.uint32) == whole.view(np.uint32)).all()
+    img, cnt = hip_render(sc, W, H, 64, b, counted=True)
+    monkeypatch.delenv("RZ_GROUPS_PER_CLAIM")
+    monkeypatch.delenv("RZ_CROSS_CLAIM_POOL")
+    osc, fr = oracle_scene(sc), oracle_frame(sc, W, H, 64, b)
+    ref = np.zeros_like(img)
+    _, rc = rzo.render(osc, fr, accum=ref, nthreads=16, want_counters=True)
+    assert cnt == rc
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all()
+    _band_check(sc, W, H, 128, b, whole)
