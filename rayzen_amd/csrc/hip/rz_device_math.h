@@ -42,10 +42,6 @@ __device__ __forceinline__ float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y
 __device__ __forceinline__ v3 cross(v3 a, v3 b) {
     return mk3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
 }
-__device__ __forceinline__ float length(v3 a) { return __builtin_sqrtf(dot(a, a)); }
-// three correctly rounded divisions (the pinned definition).  Measured: v * (1/len) instead would buy 1.6 % of C2's
-// frame time -- not worth a second rounding the oracle does not have.
-__device__ __forceinline__ v3 normalize(v3 a) { return a / __builtin_sqrtf(dot(a, a)); }
 
 __device__ __forceinline__ float fmin_(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
@@ -95,6 +91,75 @@ __device__ __forceinline__ v3 rcp3(v3 d) {
     const bool ok = okx & oky & okz;
     if (rz_ballot(!ok) == 0ull) return mk3(rcp_mid(d.x), rcp_mid(d.y), rcp_mid(d.z));
     return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+}
+
+// ---- quotients and square roots ---------------------------------------------
+// a / b and sqrt(x) must be the correctly rounded IEEE results (pinned numerics); hipcc's expansions are 11 and 13
+// instructions (31 and 42 issue cycles).  Shorter forms, each admitted only behind a range test on its operands (a wave
+// votes: one lane outside the range sends the whole wave through the compiler's expansion -- same result either way):
+//   * div_mid(a, b, r) with r = rcp_mid(b), the correctly rounded reciprocal: q0 = a r; e = fma(-q0, b, a) -- the exact
+//     residual; q = fma(e, r, q0).  Markstein's correction step; his theorem wants q0 within an ulp of a / b, which
+//     RN(a RN(1 / b)) is not proven to be, so the claim is a MEASURED one: profiles/scripts/div_sqrt_proof.hip tries 2^33
+//     random pairs, every mantissa of either operand against 64 values of the other and the exponent boundaries
+//     (tests/test_div_sqrt_gpu.py repeats it on the GPU of the test run).  Operands within [2^-60, 2^60] keep the quotient,
+//     and the residual's last bit, normal; a numerator of +0 is let through (q0 = +-0 with the quotient's sign, the residual
+//     is +0 and the final fma returns q0); -0 is not (the residual +0 would turn a quotient of -0 into +0 when b > 0).
+//     Several quotients by ONE divisor share r: normalize costs one reciprocal, not three divisions.
+//   * sqrt_mid(x): s = v_sqrt_f32(x) (1 ulp); e = fma(-s, s, x); fma(e, h, s) with h = 0.5 v_rsq_f32(x) -- PROVEN by
+//     enumeration of every x in [2^-100, 2^100] (the same program: no mismatch from 2^-102 up to the largest finite x).
+__device__ __forceinline__ bool range_ok(unsigned absbits, unsigned lo, unsigned hi) { return absbits - lo <= hi - lo; }    // lo <= absbits <= hi, one unsigned compare
+constexpr unsigned RZ_F32_2M60 = (127u - 60u) << 23, RZ_F32_2P60 = (127u + 60u) << 23, RZ_F32_2M100 = (127u - 100u) << 23, RZ_F32_2P100 = (127u + 100u) << 23;
+__device__ __forceinline__ bool div_mid_den_ok(float b) { return range_ok(__float_as_uint(b) & 0x7fffffffu, RZ_F32_2M60, RZ_F32_2P60); }
+__device__ __forceinline__ bool div_mid_num_ok(float a) {
+    const unsigned raw = __float_as_uint(a);
+    return raw == 0u || range_ok(raw & 0x7fffffffu, RZ_F32_2M60, RZ_F32_2P60);
+}
+__device__ __forceinline__ float div_mid(float a, float b, float r) {     // r = rcp_mid(b)
+    const float q0 = a * r;
+    const float e = __builtin_fmaf(-q0, b, a);
+    return __builtin_fmaf(e, r, q0);
+}
+__device__ __forceinline__ bool sqrt_mid_ok(float x) { return range_ok(__float_as_uint(x), RZ_F32_2M100, RZ_F32_2P100); }   // (negative, zero, NaN, infinity: no)
+__device__ __forceinline__ float sqrt_mid(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(x);        // (0.5 v_rcp(s) instead fails for the 100 inputs (2 - 2^-23) 4^k of the range)
+    const float e = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(e, h, s);
+}
+
+// Three numerators at once: +0, or magnitude within [2^-60, 2^60] -- the per-component test folded into integer min / max
+// (min(|bits| - lo, bits) is 0 for +0, stays out of range for -0) and ONE compare.
+__device__ __forceinline__ bool div_mid_num3_ok(v3 a) {
+    const unsigned rx = __float_as_uint(a.x), ry = __float_as_uint(a.y), rz = __float_as_uint(a.z);
+    const unsigned tx = min((rx & 0x7fffffffu) - RZ_F32_2M60, rx), ty = min((ry & 0x7fffffffu) - RZ_F32_2M60, ry), tz = min((rz & 0x7fffffffu) - RZ_F32_2M60, rz);
+    return max(max(tx, ty), tz) <= RZ_F32_2P60 - RZ_F32_2M60;
+}
+// (a.x, a.y, a.z) / b, each the correctly rounded quotient: one reciprocal and three correction steps when the wave's operands
+// are all in range, three IEEE divisions otherwise.
+__device__ __forceinline__ v3 div3(v3 a, float b) {
+    if (rz_ballot(!(div_mid_den_ok(b) && div_mid_num3_ok(a))) == 0ull) {
+        const float r = rcp_mid(b);
+        return mk3(div_mid(a.x, b, r), div_mid(a.y, b, r), div_mid(a.z, b, r));
+    }
+    return a / b;
+}
+// GLSL length / normalize with their pinned definitions, sqrt(dot(v, v)) and v / sqrt(dot(v, v)): the square root and the three
+// quotients correctly rounded, by the short forms when the wave's operands allow (dot in [2^-100, 2^100] puts the length within
+// [2^-50, 2^50], inside the divisor's range), by the compiler's expansions otherwise.  (Round 2 paid 42 + 3 x 31 issue cycles
+// per normalize for them; a closest-hit query through two instances normalizes three vectors and takes two lengths.)
+__device__ __forceinline__ float length(v3 a) {
+    const float d2 = dot(a, a);
+    if (rz_ballot(!sqrt_mid_ok(d2)) == 0ull) return sqrt_mid(d2);
+    return __builtin_sqrtf(d2);
+}
+__device__ __forceinline__ v3 normalize(v3 a) {
+    const float d2 = dot(a, a);
+    if (rz_ballot(!(sqrt_mid_ok(d2) && div_mid_num3_ok(a))) == 0ull) {
+        const float s = sqrt_mid(d2);
+        const float r = rcp_mid(s);
+        return mk3(div_mid(a.x, s, r), div_mid(a.y, s, r), div_mid(a.z, s, r));
+    }
+    return a / __builtin_sqrtf(d2);
 }
 
 // ---- sin / cos / acos -----------------------------------------------------

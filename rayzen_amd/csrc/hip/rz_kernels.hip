@@ -203,11 +203,9 @@ __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
 #ifndef RZ_GROUPS_PER_CLAIM
 #define RZ_GROUPS_PER_CLAIM 8
 #endif
-#ifdef RZ_NO_SPREAD          // (A/B aid: compile trace_spread out altogether)
-#define RZ_SPREAD_ON(K) false
-#else
-#define RZ_SPREAD_ON(K) ((K).spreadTrace != 0)
-#endif
+// trace_spread is compiled into the SPREAD flavour of the group code only (COMPACT == 1 of rz_render_samples: launches of
+// several pixels per wave): merely present in the 64-spp transparent variant it cost 8 % (c2g 24.6 -> 26.9 ms: registers).
+#define RZ_SPREAD_ON(K) (SPREAD && (K).spreadTrace != 0)
 #ifndef RZ_CLAIM_RUN_SMALL_SPP
 #define RZ_CLAIM_RUN_SMALL_SPP 1
 #endif
@@ -220,7 +218,7 @@ __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
 #ifndef RZ_COMPACT_DEFAULT
 #define RZ_COMPACT_DEFAULT 1     // compaction of late bounces across a claim (render_claim_compact); RZ_COMPACT=0/1 overrides at run time
 #endif
-template <bool COUNT, bool GLASS, bool OVF>
+template <bool COUNT, bool GLASS, bool OVF, bool SPREAD>
 __device__ __forceinline__ void render_samples_group(const KParams& K, const unsigned wblock, unsigned char* lds_raw) {
     const int lane = threadIdx.x & 63;
     // (the overflow columns are indexed by the RESIDENT workgroup: blasOvfCap > 0 only in persistent launches)
@@ -926,7 +924,7 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
     return write;
 }
 
-template <bool COUNT, bool GLASS, bool OVF, int COMPACT>      // COMPACT: 0, or the units of a compacting claim (8 / 16)
+template <bool COUNT, bool GLASS, bool OVF, int COMPACT>      // COMPACT: 0 the group code, 1 the group code with trace_spread, or the units of a compacting claim (8 / 16)
 __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES_MIN_WAVES) void rz_render_samples(const KParams K, const unsigned nGroups, const unsigned perClaim,
                                                                                                                   const unsigned nClaims, const unsigned runShift) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -934,9 +932,9 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
     const unsigned long long wl_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned wl_claims = 0;
 #endif
-    if constexpr (COMPACT == 0 || GLASS) {      // (a compacting launch always claims: its instantiations carry no copy of the group code)
+    if constexpr (COMPACT <= 1 || GLASS) {      // (a compacting launch always claims: its instantiations carry no copy of the group code)
         if (perClaim == 0) {                    // one workgroup per pixel group (small launches, spp < 64)
-            render_samples_group<COUNT, GLASS, OVF>(K, blockIdx.x, lds_raw);
+            render_samples_group<COUNT, GLASS, OVF, COMPACT == 1>(K, blockIdx.x, lds_raw);
             return;
         }
     }
@@ -950,7 +948,7 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
 #ifdef RZ_PROF
         ++wl_claims;
 #endif
-        if constexpr (COMPACT != 0 && !GLASS) {
+        if constexpr (COMPACT > 1 && !GLASS) {
             render_claim_compact<COUNT, OVF, COMPACT>(K, M, ci, lds_raw, wpN);
             if (K.wpool != nullptr) {
                 // the wave's cross-claim pool has filled up: trace it -- again if so many paths survive that the next claim's
@@ -962,10 +960,10 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
             }
         } else {
             const int n = M.units_of(ci);
-            for (int g = 0; g < n; ++g) render_samples_group<COUNT, GLASS, OVF>(K, (unsigned)M.group(ci, g), lds_raw);
+            for (int g = 0; g < n; ++g) render_samples_group<COUNT, GLASS, OVF, COMPACT == 1>(K, (unsigned)M.group(ci, g), lds_raw);
         }
     }
-    if constexpr (COMPACT != 0 && !GLASS) {
+    if constexpr (COMPACT > 1 && !GLASS) {
         // the claims have run out: what is left in the wave's pool, generation after generation (a path survives at most
         // maxBounces - 1 scatters: the bound is a backstop)
         if (K.wpool != nullptr) {
@@ -1143,7 +1141,12 @@ void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream
     if (perClaim && hipMemsetAsync(K.groupCounter, 0, sizeof(unsigned), stream) != hipSuccess) return;
     const bool ovf = K.blasOvfCap > 0;           // only set for persistent launches (rz_context.hip: render_samples)
 #define RZ_LAUNCH_SAMPLES(C, G, O, M) hipLaunchKernelGGL((rz_render_samples<C, G, O, M>), g, b, lds, stream, K, nGroups, (unsigned)perClaim, (unsigned)plan.nClaims, (unsigned)plan.runShift)
-    if (glass) {
+    // (trace_spread for the third and later segments: launches of several pixels per wave over scenes of several instances)
+    const bool spread = K.spreadTrace != 0 && K.spp < 64;
+    if (glass && spread) {
+        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, true, true, 1); else RZ_LAUNCH_SAMPLES(true, true, false, 1); }
+        else { if (ovf) RZ_LAUNCH_SAMPLES(false, true, true, 1); else RZ_LAUNCH_SAMPLES(false, true, false, 1); }
+    } else if (glass) {
         if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, true, true, 0); else RZ_LAUNCH_SAMPLES(true, true, false, 0); }
         else { if (ovf) RZ_LAUNCH_SAMPLES(false, true, true, 0); else RZ_LAUNCH_SAMPLES(false, true, false, 0); }
     } else if (compact && plan.claimUnits == RZ_CLAIM_UNITS_LARGE) {
@@ -1152,6 +1155,9 @@ void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream
     } else if (compact) {
         if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, false, true, RZ_CLAIM_UNITS_SMALL); else RZ_LAUNCH_SAMPLES(true, false, false, RZ_CLAIM_UNITS_SMALL); }
         else { if (ovf) RZ_LAUNCH_SAMPLES(false, false, true, RZ_CLAIM_UNITS_SMALL); else RZ_LAUNCH_SAMPLES(false, false, false, RZ_CLAIM_UNITS_SMALL); }
+    } else if (spread) {
+        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, false, true, 1); else RZ_LAUNCH_SAMPLES(true, false, false, 1); }
+        else { if (ovf) RZ_LAUNCH_SAMPLES(false, false, true, 1); else RZ_LAUNCH_SAMPLES(false, false, false, 1); }
     } else {
         if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, false, true, 0); else RZ_LAUNCH_SAMPLES(true, false, false, 0); }
         else { if (ovf) RZ_LAUNCH_SAMPLES(false, false, true, 0); else RZ_LAUNCH_SAMPLES(false, false, false, 0); }

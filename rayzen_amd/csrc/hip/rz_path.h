@@ -146,7 +146,7 @@ __device__ __forceinline__ void start_light(const KParams& K, Path& P, Tally& c)
     if (L.posdir[3] == 1.0f) {
         const v3 lv = mk3(L.posdir[0], L.posdir[1], L.posdir[2]) - P.hp;
         const float dist = fmax_(length(lv), 0.001f);
-        dir = (GLASS && M.transparency > 0.0f) ? lv / dist : normalize(lv);
+        dir = (GLASS && M.transparency > 0.0f) ? div3(lv, dist) : normalize(lv);
         P.maxDist = dist;
     } else {
         dir = normalize(mk3(L.posdir[0], L.posdir[1], L.posdir[2]));
@@ -191,7 +191,7 @@ __device__ __forceinline__ void shade_light(const KParams& K, Path& P) {
         const float Gv = NdotV / ((NdotV * (1.0f - k) + k) + 1e-6f);
         const float Gl = NdotL / ((NdotL * (1.0f - k) + k) + 1e-6f);
         const float denom = fmax_((4.0f * NdotL) * NdotV, 1e-4f);
-        const v3 spec = (((F * D) * Gv) * Gl) / denom;
+        const v3 spec = div3(((F * D) * Gv) * Gl, denom);
         P.lacc = P.lacc + ((spec * lcolor) * attenuation) * NdotL;
     } else {
         const v3 F0 = mk3(mix_(0.04f, albedo.x, M.metallic), mix_(0.04f, albedo.y, M.metallic),
@@ -209,9 +209,9 @@ __device__ __forceinline__ void shade_light(const KParams& K, Path& P) {
         float G = NdotV / (NdotV * (1.0f - k) + k);
         G *= NdotL / (NdotL * (1.0f - k) + k);
         const float denomSpec = fmax_((4.0f * NdotV) * NdotL, 0.0001f);
-        const v3 specular = ((F * D) * G) / denomSpec;
+        const v3 specular = div3((F * D) * G, denomSpec);
         const v3 oneMinusF = mk3(1.0f - F.x, 1.0f - F.y, 1.0f - F.z);
-        const v3 diffuse = ((oneMinusF * albedo) * NdotL) / 3.14159f;
+        const v3 diffuse = div3((oneMinusF * albedo) * NdotL, 3.14159f);
         const v3 t = ((diffuse + specular) * lcolor) * attenuation;
         P.lacc = P.lacc + mk3(fmax_(0.0f, t.x), fmax_(0.0f, t.y), fmax_(0.0f, t.z));
     }
@@ -276,7 +276,7 @@ __device__ __forceinline__ void scatter(const KParams& K, Path& P, Tally& c) {
     if (P.bounce > 2) {     // Russian roulette with the SAME random number (FS:764-769)
         const float p = fmax_(P.throughput.x, fmax_(P.throughput.y, P.throughput.z));
         if (randVal > p) { end_sample(P); RZ_T1(c, 7); return; }
-        P.throughput = P.throughput / p;
+        P.throughput = div3(P.throughput, p);
     }
     P.bounce += 1;
     if (P.bounce >= K.maxBounces) end_sample(P);

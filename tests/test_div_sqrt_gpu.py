@@ -1,0 +1,35 @@
+"""rz_device_math.h: div_mid() and sqrt_mid() stand in for the compiler's IEEE expansions of a / b (11 instructions) and
+sqrt(x) (13) wherever their admission tests hold (a wave votes; the rest take the expansions).  That is only legitimate if
+they give the correctly rounded results on the GPU at hand:
+  * sqrt_mid: EVERY admitted x (2^-100 .. 2^100: 1.68 G bit patterns) against __builtin_sqrtf -- an exhaustive proof;
+  * div_mid:  2^33 random operand pairs over the whole exponent range (the admission tests must keep zeros, denormals,
+    infinities and NaNs out), every mantissa of either operand against 64 values of the other, and the exponent boundaries
+    of the admitted range -- a measured claim (Markstein's correction step on a correctly rounded reciprocal; the 2^64
+    pairs cannot be enumerated), as VERDICT r2 item 4 asked for.
+profiles/scripts/div_sqrt_proof.hip is the program; its exit code is 0 only if both PRODUCT lines report 0 mismatches."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_short_quotient_and_square_root_are_the_ieee_results_for_every_admitted_input(tmp_path):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "div_sqrt_proof")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-I",
+                           os.path.join(root, "rayzen_amd", "csrc", "hip"), "-I", os.path.join(root, "include"), "-o", exe,
+                           os.path.join(root, "profiles", "scripts", "div_sqrt_proof.hip")], stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=400)
+    lines = {l.split(":")[0]: l for l in out.stdout.splitlines() if l.startswith("PRODUCT")}
+    assert "PRODUCT sqrt_mid" in lines and "PRODUCT div_mid" in lines, out.stdout + out.stderr
+    assert lines["PRODUCT sqrt_mid"].endswith("mismatches 0"), out.stdout
+    assert "admitted 1677721601 inputs" in lines["PRODUCT sqrt_mid"], out.stdout         # 200 exponents x 2^23 mantissas + 2^100 itself
+    assert lines["PRODUCT div_mid"].endswith("mismatches 0"), out.stdout
+    # the candidate sweeps that the product's form rests on: the one-correction quotient never missed
+    for l in out.stdout.splitlines():
+        if l.startswith("div: one correction"):
+            assert l.endswith("mismatches 0"), l
+    assert out.returncode == 0, out.stdout
