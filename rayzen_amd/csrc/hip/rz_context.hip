@@ -119,7 +119,8 @@ struct rz_ctx {
     int* relayoutPinned = nullptr;
     bool layoutOnDevice = false;        // dPairs / dTris were produced on the device (hPairs / hTris are empty)
     long long devPairsUsed = 0, devTrisUsed = 0;
-    unsigned devTransparent = 0;
+    unsigned devTransparent = 0;       // device re-layout: bit 0 a transparent material is in use, bit 1 an irregular child box
+    bool irregularBoxes = false;       // some BLAS child box has min > max or a NaN plane: the traversal keeps the generic slab test
     // rz_build_geometry: BLAS nodes / indices live in dRawNodes / dRawIdx; the host copies are fetched on demand
     bool geomOnDevice = false, geomHostFresh = false;
     size_t devNodes = 0, devIdx = 0;
@@ -250,6 +251,10 @@ int build_view(rz_ctx* c, int nodeOff, int triOff, int gTriOff, BlasView& V) {
             P.lz[0] = ln.boundsMin[2]; P.lz[1] = ln.boundsMax[2];
             P.rx[0] = rn.boundsMin[0]; P.rx[1] = rn.boundsMax[0]; P.ry[0] = rn.boundsMin[1]; P.ry[1] = rn.boundsMax[1];
             P.rz[0] = rn.boundsMin[2]; P.rz[1] = rn.boundsMax[2];
+            // (an inverted or NaN child box: the octant-specialised slab test is only the shader's test for regular boxes)
+            if (!(ln.boundsMin[0] <= ln.boundsMax[0] && ln.boundsMin[1] <= ln.boundsMax[1] && ln.boundsMin[2] <= ln.boundsMax[2] &&
+                  rn.boundsMin[0] <= rn.boundsMax[0] && rn.boundsMin[1] <= rn.boundsMax[1] && rn.boundsMin[2] <= rn.boundsMax[2]))
+                c->irregularBoxes = true;
             V.depth = std::max(V.depth, it.depth + 1);
             const rz_bvh_node* ch[2] = {&ln, &rn};
             int32_t* encs[2] = {&P.lenc, &P.renc};
@@ -450,7 +455,7 @@ int finalize_body(rz_ctx* c) {
             return fail(c, RZ_ERR_BAD_SCENE, "BLAS node array holds %zu nodes; the limit is %zu", nodesNow, ((size_t)1 << 27) - 1);
         c->views.clear(); c->hPairs.clear(); c->hTris.clear(); c->instDirty = true;
         c->triNValid = -1;
-        c->devPairsUsed = c->devTrisUsed = 0; c->devTransparent = 0;
+        c->devPairsUsed = c->devTrisUsed = 0; c->devTransparent = 0; c->irregularBoxes = false;
         c->layoutOnDevice = !host_relayout_forced(c);
         if (c->layoutOnDevice) { int rc = prepare_device_relayout(c); if (rc != RZ_OK) return rc; }
     }
@@ -574,9 +579,10 @@ int finalize_body(rz_ctx* c) {
                                                                nMat, c->dRelayoutWs.p, c->relayoutPinned, &tr, &detail, c->stream);
                 if (rc < 0) return fail(c, RZ_ERR_HIP, "material check: %s", hipGetErrorString((hipError_t)(-rc)));
                 if (rc > 0) return fail(c, RZ_ERR_BAD_SCENE, "triangle %d has a materialIndex outside the %d materials uploaded", detail, nMat);
-                c->devTransparent = tr;
+                c->devTransparent = (c->devTransparent & 2u) | (tr & 1u);
             }
-            transparent = c->devTransparent != 0;
+            transparent = (c->devTransparent & 1u) != 0;
+            c->irregularBoxes = (c->devTransparent & 2u) != 0;
         } else {
             for (const DevTri& t : c->hTris) {
                 if (t.mat < 0 || t.mat >= nMat)
@@ -745,6 +751,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
         long long minInst = RZ_SPREAD_MIN_INSTANCES;
         if (const char* e = std::getenv("RZ_SPREAD_MIN_INSTANCES")) minInst = std::atoll(e);
         K.spreadTrace = (minInst > 0 && nIdx >= minInst) ? 1 : 0;
+        K.regularBoxes = c->irregularBoxes ? 0 : 1;
     }
     const size_t perWave = (size_t)K.blasStackCap * 512 + (size_t)K.tlasStackCap * 256 + 4864;
     if (perWave * 4 > 160 * 1024)   // sized for the largest (4-wave) workgroup

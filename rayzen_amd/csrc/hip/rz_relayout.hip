@@ -27,7 +27,7 @@
 
 namespace rz {
 
-struct RelayoutErr { int code; int detail; unsigned transparent; int maxSlot; };   // device word block
+struct RelayoutErr { int code; int detail; unsigned transparent; int maxSlot; };   // device word block (transparent: bit 0 a transparent material is in use, bit 1 an irregular child box was laid out)
 enum : int { RL_OK = 0, RL_BAD_CHILD = 1, RL_BAD_LEAF = 2, RL_BAD_TRI = 3, RL_BAD_MAT = 4, RL_NOT_A_TREE = 5 };
 
 namespace {
@@ -67,6 +67,11 @@ __global__ void rl_write(const rz_bvh_node* __restrict__ nodes, long long nView,
     P.rx[0] = rn.boundsMin[0]; P.rx[1] = rn.boundsMax[0]; P.ry[0] = rn.boundsMin[1]; P.ry[1] = rn.boundsMax[1];
     P.rz[0] = rn.boundsMin[2]; P.rz[1] = rn.boundsMax[2];
     P.pad[0] = 0; P.pad[1] = 0;
+    // a child box with min > max on some axis, or a NaN plane: the octant-specialised slab test (rz_trace.h: slab_finish<OCT>)
+    // picks tmin / tmax by the ray's octant instead of by min / max and is only the shader's test for regular boxes
+    if (!(ln.boundsMin[0] <= ln.boundsMax[0] && ln.boundsMin[1] <= ln.boundsMax[1] && ln.boundsMin[2] <= ln.boundsMax[2] &&
+          rn.boundsMin[0] <= rn.boundsMax[0] && rn.boundsMin[1] <= rn.boundsMax[1] && rn.boundsMin[2] <= rn.boundsMax[2]))
+        atomicOr(&err->transparent, 2u);
     int enc[2];
     const rz_bvh_node* ch[2] = {&ln, &rn};
     for (int c = 0; c < 2; ++c) {

@@ -134,6 +134,7 @@ struct KParams {
     float* daddends;        // [claim][unit][6][64]: the addends of the claims whose pixels wait for parked paths
     int32_t* dflags;        // [claim] 1: waiting (summed by rz_deferred_sums)
     uint32_t dClaimStride;  // floats per claim in daddends (units of a claim x 384)
+    int32_t regularBoxes;   // 1: every BLAS child box has min <= max on every axis (no NaN): the octant-specialised slab test may be used
 };
 
 // Arguments of the device TLAS rebuild (rz_tlas_device.hip: rz_tlas_refit; filled in by rz_context.hip).

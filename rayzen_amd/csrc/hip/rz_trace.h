@@ -453,7 +453,7 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
         const int oct = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
         const unsigned long long walkers = rz_ballot(go);
         int uoct = -1;
-        if (walkers != 0ull) {
+        if (walkers != 0ull && K.regularBoxes != 0) {       // (an inverted or NaN child box would be hit by the shader's min / max and missed by the octant's choice)
             const int first = __builtin_amdgcn_readlane(oct, (int)__builtin_ctzll(walkers));
             if (rz_ballot(go && (!fin || oct != first)) == 0ull) uoct = first;
         }

@@ -396,3 +396,33 @@ def test_persistent_launch_glass_scene_chunked_and_windowed(monkeypatch):
     o = np.zeros_like(one)
     rzo.render(oracle_scene(sc), oracle_frame(sc, W, H, 128, b), accum=o, crop=(0, y0, W, y0 + 8), nthreads=16)
     assert (one[y0:y0 + 8].view(np.uint32) == o[y0:y0 + 8].view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+def test_inverted_and_nan_child_boxes_take_the_generic_slab_test(flags):
+    """the octant-specialised slab test picks tmin / tmax by the ray's octant, which equals the shader's per-axis
+    min / max (FS:384-385) only for boxes with min <= max.  Caller-uploaded BLAS nodes are not validated for that, so a scene
+    with an inverted or NaN child box must keep the generic test -- detected while the pairs are laid out, on the device
+    (flags 0) and on the host (RZ_FLAG_HOST_RELAYOUT = 4) -- and rz_render, rz_render_counted and the oracle must agree."""
+    from rayzen_amd.renderer import Renderer, frame_params
+    sc = S.bunny_scene(n=8)
+    nodes = sc.arrays[S.BIND_BLAS_NODES]
+    inner = [i for i in range(len(nodes)) if nodes["count"][i] < 0]
+    # swap min and max of a few children on one axis, and put a NaN into another child's box
+    for k, i in enumerate(inner[3:9]):
+        c = nodes["leftFirst"][i] + (k & 1)
+        a = k % 3
+        lo, hi = nodes["boundsMin"][c][a], nodes["boundsMax"][c][a]
+        nodes["boundsMin"][c][a], nodes["boundsMax"][c][a] = hi, lo
+    nodes["boundsMax"][nodes["leftFirst"][inner[12]]][1] = np.nan
+    W, H, spp, b = 96, 64, 8, 4
+    ref = oracle_render(sc, W, H, spp, b)
+    r = Renderer(0, flags)
+    got = hip_render(sc, W, H, spp, b, renderer=r)
+    r.set_frame(frame_params(sc.camera, W, H, len(sc.lights), b, spp))
+    r.clear_accum()
+    r.render_counted()
+    counted = r.read_accum()
+    r.close()
+    _eq(got, ref)
+    _eq(counted, ref)

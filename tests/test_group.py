@@ -93,3 +93,42 @@ def test_cpp_group_example_is_bit_identical_to_a_single_context(tmp_path):
     out = subprocess.run([exe, "0", "160", "96", "3"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "bit-identical" in out.stdout
+
+
+@pytest.mark.gpu
+def test_two_contexts_on_two_devices_interleaved():
+    """a context may be driven while ANOTHER device is current (the members of a one-process group).  Every exported
+    entry point binds its context's device first (guarded(), rz_context.hip); without that, resolve / present / counters of a
+    member allocate and launch on the wrong GPU.  Needs two devices: skipped on the one-GPU test box, run by whoever has a node."""
+    L = _lib.hip()
+    if L.rz_device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    from rayzen_amd import scene as S
+    from rayzen_amd.renderer import Renderer, frame_params
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from helpers import oracle_render
+    sc = S.bunny_scene(n=6, extras=True)
+    W, H, spp, b = 64, 40, 4, 4
+    ref = oracle_render(sc, W, H, spp, b)
+    rs = [Renderer(0), Renderer(1)]
+    for r in rs:
+        r.upload_scene(sc)
+        r.set_frame(frame_params(sc.camera, W, H, len(sc.lights), b, spp))
+    rs[0].render(); rs[1].render_counted(); rs[0].resolve_rgba8(); rs[1].present(); rs[1].clear_accum(); rs[1].render()
+    rs[0].clear_accum(); rs[0].render_counted()
+    for r in rs:
+        got = r.read_accum()
+        assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+        r.close()
+    # the one-process group over both devices: tiles dealt to two ranks, one RCCL reduce
+    g = D.Group.create(2)
+    assert g.size == 2 and g.local_count == 2
+    g.upload_scene(sc)
+    g.set_frame(frame_params(sc.camera, W, H, len(sc.lights), b, spp))
+    g.render(); g.reduce(0); g.sync()
+    frame = g.read_frame()
+    root_ms, max_ms = g.last_reduce_ms()
+    g.close()
+    assert (frame.view(np.uint32) == ref.view(np.uint32)).all()
+    assert root_ms >= 0.0 and max_ms >= root_ms
