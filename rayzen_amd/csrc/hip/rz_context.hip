@@ -667,7 +667,7 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     if (plan.crossClaimPool && K.claimScratch != nullptr && K.maxBounces > 2) {
         // every resident wave keeps its pool of parked paths across claims: room for the chunk it collects before it traces
         // them + the most one more claim can park; the addends of every claim (only the waiting ones are written) and a
-        // flag per claim
+        // link per claim (each wave's list of its waiting claims; written before it is read, so never cleared)
         long long chunk = RZ_WPOOL_CHUNK;
         if (const char* e = std::getenv("RZ_WPOOL_CHUNK")) chunk = std::max<long long>(1, std::atoll(e));      // tuning / test aid
         const size_t stride = (size_t)chunk + (size_t)plan.claimUnits * 64 + 64;
@@ -678,7 +678,6 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
         if (rc != RZ_OK) return rc;
         rc = ensure(c, c->dDeferFlags, (size_t)plan.nClaims * sizeof(int32_t));
         if (rc != RZ_OK) return rc;
-        RZ_HIP(c, hipMemsetAsync(c->dDeferFlags.p, 0, (size_t)plan.nClaims * sizeof(int32_t), c->stream));
         K.wpool = static_cast<unsigned*>(c->dGPool[0].p);
         K.wpoolStride = (uint32_t)stride;
         K.wpoolChunk = (uint32_t)chunk;

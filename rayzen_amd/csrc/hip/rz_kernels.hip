@@ -535,8 +535,8 @@ struct ClaimMap {
 // The ordered sums of a claim's pixels from its addends ([unit][6][64] floats at addBase): 21 pixels per pass, lane 3 q + ch
 // replays the additions of channel ch of the pass's q-th pixel in sample order, FS:717 then FS:709, sample after sample
 // (spp >= 64: a claim has at most 16 pixels -- one pass, 24 or 48 lanes busy; spp < 64: up to 64 pixels per unit, each summing
-// its spp entries of one unit's addends).  Run at the end of a claim, or by rz_deferred_sums once the claim's parked paths
-// have come back from the launch's global pool.
+// its spp entries of one unit's addends).  Run at the end of a claim, or -- for a claim that waited for parked paths -- by its wave at the end of the launch, when
+// the wave's pool has run dry.
 template <bool COUNT>
 __device__ __forceinline__ void claim_ordered_sums(const KParams& K, const ClaimMap& M, const unsigned ci, const float* __restrict__ addBase,
                                                    const int nPix, const int ppw, const int nBatches) {
@@ -610,7 +610,7 @@ __device__ __forceinline__ void claim_ordered_sums(const KParams& K, const Claim
 // Scratch is private to the resident wave and is only ever read by the wave that wrote it (L1/L2 hits); the
 // __syncthreads() of the one-wave workgroup order its stores before its loads.
 template <bool COUNT, bool OVF, int UNITS>
-__device__ __forceinline__ void render_claim_compact(const KParams& K, const ClaimMap M, const unsigned ci, unsigned char* lds_raw, int& wpN) {
+__device__ __forceinline__ void render_claim_compact(const KParams& K, const ClaimMap M, const unsigned ci, unsigned char* lds_raw, int& wpN, int& wpHead) {
     const int lane = threadIdx.x & 63;
     const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + lane,
                                OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + lane : nullptr, K.blasStackCap};
@@ -765,11 +765,13 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
             if (unit >= nUnits) {
                 __syncthreads();       // the pool is read next
                 if (crossClaim && nPool > 0) {
-                    // the claim's pixels wait for its parked paths: its addends move to the launch's buffer (rz_deferred_sums
-                    // adds them up when every path is back) and the wave goes on to its next claim
+                    // the claim's pixels wait for its parked paths: its addends move to the launch's buffer, the claim joins the
+                    // list of this wave's waiting claims (linked through K.dflags, newest first: the paths are in THIS wave's
+                    // pool, so the wave itself adds the pixels up once its pool has run dry) and the wave goes on
                     float* const D = K.daddends + (size_t)ci * K.dClaimStride;
                     for (int k = lane; k < nUnits * 384; k += 64) D[k] = addBase[k];
-                    if (lane == 0) K.dflags[ci] = 1;
+                    if (lane == 0) K.dflags[ci] = wpHead;
+                    wpHead = (int)ci + 1;
                     wpN += nPool;
                     deferred = true;
                     claimDeferred = true;
@@ -825,8 +827,8 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
 // leave their addends in K.daddends, and when the pool holds K.wpoolChunk paths (and when the claims have run out) the wave
 // traces ALL of them together, shades them 64 at a time (the late part of the shader's bounce loop, FS:705-711 / 720-769:
 // sky and the end, or scatter and Russian roulette), writes the sky term of the paths that end to their samples' slots and
-// keeps the survivors, compacted in place (ballot + prefix popcount), for the next time.  rz_deferred_sums then replays
-// the ordered sums of the claims that waited.  Late work and coherent work so run side by side on a CU all through the
+// keeps the survivors, compacted in place (ballot + prefix popcount), for the next time.  When the claims have run out and
+// the pool has run dry, the wave replays the ordered sums of ITS claims that waited (a list linked through K.dflags).  Late work and coherent work so run side by side on a CU all through the
 // launch -- the late rays keep the texture-address unit busy (64 B per lane and step whatever the ray), the coherent ones
 // the issue slots -- and no queue is shared between waves: nothing to synchronise, nothing to wait for.
 // A path's arithmetic does not depend on the lane, wave or moment that runs it: same bits as every other launch shape.
@@ -940,6 +942,7 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
     }
     const ClaimMap M{nGroups, perClaim, nClaims, runShift};
     int wpN = 0;                                // paths in this wave's cross-claim pool
+    int wpHead = 0;                             // ... and the newest of the claims that wait for them (index + 1; 0: none), linked through K.dflags
     for (;;) {
         unsigned ci = 0;
         if ((threadIdx.x & 63) == 0) ci = atomicAdd(K.groupCounter, 1u);
@@ -949,7 +952,7 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
         ++wl_claims;
 #endif
         if constexpr (COMPACT > 1 && !GLASS) {
-            render_claim_compact<COUNT, OVF, COMPACT>(K, M, ci, lds_raw, wpN);
+            render_claim_compact<COUNT, OVF, COMPACT>(K, M, ci, lds_raw, wpN, wpHead);
             if (K.wpool != nullptr) {
                 // the wave's cross-claim pool has filled up: trace it -- again if so many paths survive that the next claim's
                 // could not be parked behind them (every pass moves its paths one bounce on: the bound is a backstop)
@@ -971,6 +974,19 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
                                        OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + (threadIdx.x & 63) : nullptr, K.blasStackCap};
             for (int guard = 0; wpN > 0 && guard <= K.maxBounces; ++guard)
                 wpN = pool_process<COUNT, OVF>(K, K.wpool + (size_t)blockIdx.x * K.wpoolStride * RZ_GPOOL_FIELDS, K.wpoolStride, wpN, bstk);
+            // every path of this wave's claims is back: the ordered sums of the claims that waited (their addends, sky terms
+            // included, are in K.daddends); the list cannot be longer than the claims of the launch
+            const int spp = K.spp, nBatches = (spp + 63) / 64, ppw = spp >= 64 ? 1 : 64 / spp;
+            unsigned walked = 0;
+            for (int h = wpHead; h != 0 && walked <= nClaims; ++walked) {
+                const unsigned ci = (unsigned)(h - 1);
+                claim_ordered_sums<COUNT>(K, M, ci, K.daddends + (size_t)ci * K.dClaimStride, M.units_of(ci) * ppw, ppw, nBatches);
+                // (read at device scope, past the scalar and vector L1 caches: the links of other waves' claims share cache lines with
+                //  this wave's, and a line cached before this wave stored its link would still hold the old word)
+                int nxt = 0;
+                if ((threadIdx.x & 63) == 0) nxt = __hip_atomic_load(K.dflags + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                h = __builtin_amdgcn_readfirstlane(nxt);
+            }
         }
     }
 #ifdef RZ_PROF
@@ -980,19 +996,6 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
         rz_wave_log[blockIdx.x][2] = wl_claims;
     }
 #endif
-}
-
-template <bool COUNT>
-__global__ __launch_bounds__(64) void rz_deferred_sums(const KParams K, const unsigned nGroups, const unsigned perClaim, const unsigned nClaims, const unsigned runShift) {
-    const ClaimMap M{nGroups, perClaim, nClaims, runShift};
-    const int spp = K.spp;
-    const int nBatches = (spp + 63) / 64;
-    const int ppw = spp >= 64 ? 1 : 64 / spp;
-    for (unsigned ci = blockIdx.x; ci < nClaims; ci += gridDim.x) {
-        if (sload1(K.dflags + ci) == 0) continue;
-        const int nPix = M.units_of(ci) * ppw;
-        claim_ordered_sums<COUNT>(K, M, ci, K.daddends + (size_t)ci * K.dClaimStride, nPix, ppw, nBatches);
-    }
 }
 
 // FS:772-773 + 8-bit quantisation: rgba8 = round(clamp(sum / n, 0, 1) * 255), a = 255.
@@ -1163,12 +1166,6 @@ void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream
         else { if (ovf) RZ_LAUNCH_SAMPLES(false, false, true, 0); else RZ_LAUNCH_SAMPLES(false, false, false, 0); }
     }
 #undef RZ_LAUNCH_SAMPLES
-    if (compact && K.wpool != nullptr) {
-        // the ordered sums of the claims that waited for parked paths -- same stream, right behind the render kernel
-        const dim3 gs((unsigned)std::min<long long>(plan.nClaims, grid * 4));
-        if (counted) hipLaunchKernelGGL((rz_deferred_sums<true>), gs, b, 0, stream, K, nGroups, (unsigned)perClaim, (unsigned)plan.nClaims, (unsigned)plan.runShift);
-        else hipLaunchKernelGGL((rz_deferred_sums<false>), gs, b, 0, stream, K, nGroups, (unsigned)perClaim, (unsigned)plan.nClaims, (unsigned)plan.runShift);
-    }
 }
 
 // The local hemisphere direction of a zero seed (rz_path.h: random_hemisphere_direction), by the kernels' own arithmetic.

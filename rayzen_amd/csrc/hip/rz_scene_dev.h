@@ -132,7 +132,7 @@ struct KParams {
     uint32_t wpoolStride;   // slots per field: wpoolChunk + the most one claim can park
     uint32_t wpoolChunk;    // the wave traces its pool when it holds at least this many paths (and at the end of the launch)
     float* daddends;        // [claim][unit][6][64]: the addends of the claims whose pixels wait for parked paths
-    int32_t* dflags;        // [claim] 1: waiting (summed by rz_deferred_sums)
+    int32_t* dflags;        // [claim] the next older waiting claim of the same wave (index + 1; 0: none): the wave sums them at the end of the launch
     uint32_t dClaimStride;  // floats per claim in daddends (units of a claim x 384)
     int32_t regularBoxes;   // 1: every BLAS child box has min <= max on every axis (no NaN): the octant-specialised slab test may be used
 };

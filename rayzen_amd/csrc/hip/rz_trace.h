@@ -692,6 +692,9 @@ static_assert(poolf::ITINST + 1 == RZ_POOL_FIELDS, "pool fields");
 #ifndef RZ_REFILL_MIN_LANES
 #define RZ_REFILL_MIN_LANES 8      // idle lanes it takes to interrupt the walk for a refill (unless nobody walks at all)
 #endif
+#ifndef RZ_POOL_DESCEND_MIN_LANES
+#define RZ_POOL_DESCEND_MIN_LANES 4    // the pool's walks leave the descend loop for the leaves when fewer lanes than this still descend
+#endif
 #ifndef RZ_TAIL_LANES
 #define RZ_TAIL_LANES 16           // a B phase whose list has run out ends when fewer lanes than this still walk (they go on in the next one)
 #endif
@@ -893,7 +896,7 @@ __device__ __forceinline__ void pool_trace(const KParams& K, unsigned* __restric
                     cur = nxt;
                 }
                 actMask = rz_ballot(cur >= 0);
-                more = mask_count(actMask) >= RZ_DESCEND_MIN_LANES;
+                more = mask_count(actMask) >= RZ_POOL_DESCEND_MIN_LANES;
             }
             // -- leaves
             const unsigned long long alive = rz_ballot((cur != -1) || (sp > 0));

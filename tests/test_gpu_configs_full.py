@@ -303,7 +303,7 @@ def test_compacting_launch_below_64_spp_continued_frames_tile_ranks_and_counters
     assert (img.view(np.uint32) == ref.view(np.uint32)).all()
 
 
-# ---- the pool a wave keeps ACROSS its claims (round 3: pool_process / pool_trace / rz_deferred_sums) -------------------------
+# ---- the pool a wave keeps ACROSS its claims (round 3: pool_process / pool_trace) -------------------------
 
 @pytest.mark.parametrize("W,H,spp,claim,chunk", [(640, 512, 64, 8, None), (643, 509, 100, 4, None), (640, 512, 16, 8, None), (323, 253, 5, 3, None),
                                                  (640, 512, 128, 8, 3000), (640, 512, 16, 16, 777), (640, 512, 64, 8, 64), (640, 512, 64, 8, 1)])
@@ -311,7 +311,7 @@ def test_cross_claim_pool_equals_the_per_claim_pools_and_the_oracle(W, H, spp, c
     """The waves of a large opaque launch do not work a claim's parked paths off before the next claim: they collect in the
     wave's own pool, third and later segments side by side, and are traced together when `chunk` of them have come together
     (lanes refilling from the list of pending BLAS walks: pool_trace) and at the end of the launch; the claims that wait
-    leave their addends behind and rz_deferred_sums replays their ordered sums.  Forced here on small frames
+    leave their addends behind and their wave replays their ordered sums when its pool has run dry.  Forced here on small frames
     (RZ_CROSS_CLAIM_POOL=1 + claims by RZ_GROUPS_PER_CLAIM) with chunks from 1 (every claim) to 3000 (the end of the launch
     only), sizes that are not multiples of 64, and several pixels per wave: every shape must give the image of the per-claim
     pools, of one workgroup per group, and of the oracle.  6 bounces: paths survive several passes of a pool.
