@@ -12,7 +12,7 @@ from helpers import hip_render, oracle_render, mismatch_report
 pytestmark = pytest.mark.gpu
 
 
-def random_scene(seed):
+def random_scene(seed, opaque=False):
     rng = np.random.default_rng(seed)
     nm = int(rng.integers(3, 9))
     mats = np.zeros(nm, S.MATERIAL)
@@ -23,6 +23,8 @@ def random_scene(seed):
         m["reflectivity"] = rng.choice([0.0, 0.0, 1.0, rng.uniform()])
         m["transparency"] = rng.choice([0.0, 0.0, 0.0, 0.9, 1.0, rng.uniform()])
         m["ior"] = rng.choice([1.0, 1.33, 1.5, 2.4])
+        if opaque:
+            m["transparency"] = 0.0
     nl = int(rng.integers(0, 4))
     lights = np.zeros(nl, S.LIGHT)
     for l in lights:
@@ -90,3 +92,35 @@ def test_random_scene_large_frame_persistent_path(seed):
         rzo.render(oracle_scene(sc), oracle_frame(sc, W, H, spp, b), accum=ref, crop=(0, y0, W, y0 + 8), nthreads=16)
         assert (gpu[y0:y0 + 8].view(np.uint32) == ref[y0:y0 + 8].view(np.uint32)).all(), \
             f"seed {seed}: " + mismatch_report(gpu[y0:y0 + 8], ref[y0:y0 + 8])
+
+
+N_CLAIMS = int(os.environ.get("RZ_FUZZ_CLAIM_SEEDS", "96"))      # (a soak of 400 on the round-3 build: bit-identical)
+
+
+@pytest.mark.parametrize("seed", range(N_CLAIMS))
+def test_random_opaque_scene_through_claims_and_cross_claim_pools(seed, monkeypatch):
+    """The round-3 launch machinery on random opaque scenes, forced onto frames small enough for the oracle: persistent
+    compacting claims of 2 ... 16 groups (stratified or in runs), at 1 ... 130 spp (several pixels per wave, also when the spp does
+    not divide 64; several batches per pixel), parked paths kept in the waves' pools across claims and traced whenever a pool
+    holds 24 ... 200 of them (so that pools are traced in the middle of a launch, more than once, and at its end), trace_spread
+    for the scenes of three and more instances.  Every pixel against the oracle, bit for bit."""
+    sc, rng = random_scene(5000 + seed, opaque=True)
+    W, H = int(rng.integers(40, 161)), int(rng.integers(24, 97))
+    spp, b = int(rng.choice([1, 2, 3, 8, 16, 17, 40, 64, 100, 130])), int(rng.integers(3, 9))
+    sc.camera.aspect = W / H
+    sc.camera.update()
+    per_claim = int(rng.choice([2, 4, 8, 16]))
+    monkeypatch.setenv("RZ_GROUPS_PER_CLAIM", str(per_claim))
+    monkeypatch.setenv("RZ_CLAIM_RUN", str(int(rng.choice([1, 2, per_claim]))))
+    monkeypatch.setenv("RZ_CROSS_CLAIM_POOL", "1")
+    monkeypatch.setenv("RZ_WPOOL_CHUNK", str(int(rng.choice([24, 64, 200]))))
+    from rayzen_amd.renderer import Renderer
+    r = Renderer(0)
+    gpu = hip_render(sc, W, H, spp, b, renderer=r)
+    plan = r.debug_last_plan()
+    name = r.last_kernel_name()
+    r.close()
+    assert plan["per_claim"] > 0 and plan["claim_units"] in (8, 16), plan        # the launch did take compacting claims
+    assert name == "rz_render_samples+pool", name
+    ref = oracle_render(sc, W, H, spp, b, nthreads=16)
+    assert (gpu.view(np.uint32) == ref.view(np.uint32)).all(), f"seed {seed} ({W}x{H}, {spp} spp, {b} bounces, claims of {per_claim}): " + mismatch_report(gpu, ref)
