@@ -83,7 +83,7 @@ struct rz_ctx {
     long long triNValid = -1;       // triangles dTriN holds normals for (-1: none; reset with the geometry)
     long long lastGrid = 0;         // workgroups of the last render launch (RZ_PROF: how many wave-log entries are valid)
     rz_launch_plan lastPlan{};      // rz_debug_last_plan
-    bool lastGlobalPool = false;    // the last launch kept one pool of parked paths for all its claims (rz_late_generation)
+    bool lastGlobalPool = false;    // the last launch's waves kept their pools of parked paths across claims (rz_kernels.hip: pool_process)
     std::string err;
 
     // host copies of the caller's arrays (the re-layout needs them; rz_update patches them)
@@ -115,7 +115,7 @@ struct rz_ctx {
     int failAllocCountdown = 0;         // rz_debug_fail_alloc (test hook)
     // device re-layout (rz_relayout.hip): the caller's raw arrays on the device, the fill of dPairs / dTris, scratch
     DevBuf dRawNodes, dRawIdx, dRawTris, dRelayoutWs, dClaimScratch;
-    DevBuf dGPool[2], dGCounts, dDeferAdd, dDeferFlags;     // the waves' cross-claim pools of parked paths, the waiting claims' addends and flags (rz_kernels.hip: pool_process)
+    DevBuf dWavePools, dDeferAdd, dDeferFlags;     // the waves' cross-claim pools of parked paths, the waiting claims' addends and flags (rz_kernels.hip: pool_process)
     int* relayoutPinned = nullptr;
     bool layoutOnDevice = false;        // dPairs / dTris were produced on the device (hPairs / hTris are empty)
     long long devPairsUsed = 0, devTrisUsed = 0;
@@ -671,14 +671,14 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
         long long chunk = RZ_WPOOL_CHUNK;
         if (const char* e = std::getenv("RZ_WPOOL_CHUNK")) chunk = std::max<long long>(1, std::atoll(e));      // tuning / test aid
         const size_t stride = (size_t)chunk + (size_t)plan.claimUnits * 64 + 64;
-        rc = ensure(c, c->dGPool[0], (size_t)plan.grid * stride * RZ_GPOOL_FIELDS * sizeof(unsigned));
+        rc = ensure(c, c->dWavePools, (size_t)plan.grid * stride * RZ_GPOOL_FIELDS * sizeof(unsigned));
         if (rc != RZ_OK) return rc;
         const size_t claimFloats = (size_t)plan.claimUnits * 384;
         rc = ensure(c, c->dDeferAdd, (size_t)plan.nClaims * claimFloats * sizeof(float));
         if (rc != RZ_OK) return rc;
         rc = ensure(c, c->dDeferFlags, (size_t)plan.nClaims * sizeof(int32_t));
         if (rc != RZ_OK) return rc;
-        K.wpool = static_cast<unsigned*>(c->dGPool[0].p);
+        K.wpool = static_cast<unsigned*>(c->dWavePools.p);
         K.wpoolStride = (uint32_t)stride;
         K.wpoolChunk = (uint32_t)chunk;
         K.daddends = static_cast<float*>(c->dDeferAdd.p);
@@ -804,7 +804,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
             fprintf(stderr, "[rz_prof] %-16s wave-execs %12llu  lanes %14llu  avg active lanes %.1f\n", names[k], pr[2 * k], pr[2 * k + 1], pr[2 * k] ? (double)pr[2 * k + 1] / (double)pr[2 * k] : 0.0);
         fprintf(stderr, "[rz_prof] wave cycles: begin %llu  trace %llu  advance %llu | inside trace: descend loops %llu  leaf phases %llu  whole BLAS walks %llu\n", pr[16], pr[17], pr[18], pr[19], pr[20], pr[21]);
         fprintf(stderr, "[rz_prof] compacting claims: phase 1 (units) %llu  pool rounds %llu wave cycles; %llu rounds with %llu paths = %.1f lanes per round\n", pr[23], pr[28], pr[29], pr[30], pr[29] ? (double)pr[30] / (double)pr[29] : 0.0);
-        fprintf(stderr, "[rz_prof] late generations: %llu chunks, %llu queries, shade rounds %llu wave cycles\n", pr[29], pr[30], pr[28]);
+        fprintf(stderr, "[rz_prof] cross-claim pools: %llu traced, %llu queries in them, shade rounds %llu wave cycles\n", pr[29], pr[30], pr[28]);
         fprintf(stderr, "[rz_prof] pool_trace (a claim's pooled queries traced together): %llu wave cycles = T phases %llu + B phases %llu (of which refills %llu); round 7 above = its steps\n", pr[120], pr[121], pr[122], pr[123]);
         fprintf(stderr, "[rz_prof] inside advance: sky %llu  hit %llu  start_light %llu  shade_light %llu  scatter %llu (hemisphere %llu)  shadow step %llu\n", pr[22], pr[23], pr[24], pr[25], pr[26], pr[27], pr[28]);
 #endif
@@ -878,7 +878,7 @@ void rz_destroy(rz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
-                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs, &c->dTlasDfs, &c->dTriN, &c->dRawNodes, &c->dRawIdx, &c->dRawTris, &c->dRelayoutWs, &c->dClaimScratch, &c->dGPool[0], &c->dGPool[1], &c->dGCounts, &c->dDeferAdd, &c->dDeferFlags})
+                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs, &c->dTlasDfs, &c->dTriN, &c->dRawNodes, &c->dRawIdx, &c->dRawTris, &c->dRelayoutWs, &c->dClaimScratch, &c->dWavePools, &c->dDeferAdd, &c->dDeferFlags})
         b->release();
     if (c->tlasHostCounts) (void)hipHostFree(c->tlasHostCounts);
     if (c->relayoutPinned) (void)hipHostFree(c->relayoutPinned);

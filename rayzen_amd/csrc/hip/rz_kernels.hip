@@ -637,7 +637,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
     Tally c = {};
     unsigned guard = 0;
     bool cont;
-    bool claimDeferred = false;     // wave-uniform: the claim's parked paths went to the launch's global pool (its pixels are summed later)
+    bool claimDeferred = false;     // wave-uniform: the claim's parked paths went to the wave's cross-claim pool (its pixels are summed later)
     do {                                                        // (one exit, at the end: see blas_walk; the bound is a backstop: units + pool rounds of at most maxBounces generations)
         const bool phase2 = unit >= nUnits;
         Path P;         // (per round: nothing of a path lives across rounds -- declared outside, all its fields stayed allocated across pool_trace)
@@ -716,9 +716,8 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
                 RZ_SITE(c, 6);
                 const unsigned long long tq0_ = __builtin_amdgcn_s_memtime();
 #endif
-                // (a claim's own pool -- small launches, and claims that found the launch's global pool full -- is worked off 64
-                //  paths at a time by the wave-cursor walk, as in round 2; the lane-refilling tracer needs a list much longer than
-                //  a claim's few dozen paths: rz_late_generation)
+                // (a claim's own pool -- small launches -- is worked off 64 paths at a time by the wave-cursor walk, as in round 2:
+                //  the lane-refilling tracer needs a list much longer than a claim's few dozen paths, see pool_process)
                 const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, c);
 #ifdef RZ_PROF
                 c.rt[c.rnd & 7] += __builtin_amdgcn_s_memtime() - tq0_;

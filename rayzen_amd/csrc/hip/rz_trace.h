@@ -699,8 +699,7 @@ static_assert(poolf::ITINST + 1 == RZ_POOL_FIELDS, "pool fields");
 #define RZ_TAIL_LANES 16           // a B phase whose list has run out ends when fewer lanes than this still walk (they go on in the next one)
 #endif
 
-// pool: field f of slot s is pool[f * PS + s] (PS: the wave's own pool in the claim scratch, or the capacity of the launch's
-// global pool when a chunk of it is traced in place).
+// pool: field f of slot s is pool[f * PS + s] (PS: the capacity of the wave's pool).
 template <bool COUNT, bool OVF>
 __device__ __forceinline__ void pool_trace(const KParams& K, unsigned* __restrict__ pool, const size_t PS, const int nQ, const BlasStackT<OVF>& bstk, Tally& c) {
     using namespace poolf;
