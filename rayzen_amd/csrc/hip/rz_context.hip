@@ -184,6 +184,19 @@ int ensure(rz_ctx* c, DevBuf& b, size_t bytes) {
     return RZ_OK;
 }
 
+// Scratch a launch can do without (the cross-claim pools: without them a claim works its parked paths off by itself, as in
+// round 2): taken only if it leaves at least half of the device's free memory to the caller, and a refusal is not an error.
+bool ensure_optional(DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return true;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (bytes > (freeB + b.cap) / 2) return false;
+    b.release();
+    if (hipMalloc(&b.p, std::max<size_t>(bytes, 256)) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; b.cap = 0; return false; }
+    b.cap = std::max<size_t>(bytes, 256);
+    return true;
+}
+
 int upload_vec(rz_ctx* c, DevBuf& b, const void* src, size_t bytes) {
     int rc = ensure(c, b, bytes);
     if (rc != RZ_OK) return rc;
@@ -670,20 +683,22 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
         // link per claim (each wave's list of its waiting claims; written before it is read, so never cleared)
         long long chunk = RZ_WPOOL_CHUNK;
         if (const char* e = std::getenv("RZ_WPOOL_CHUNK")) chunk = std::max<long long>(1, std::atoll(e));      // tuning / test aid
+        // (the addends array is 1.5 KB per unit of the launch -- 3.2 GB for a 1080p frame at 64 spp, 25 GB for 4K at 128 spp -- of
+        //  which only the waiting claims' parts are touched: sized for a 288-GB part, and done without where it does not fit)
         const size_t stride = (size_t)chunk + (size_t)plan.claimUnits * 64 + 64;
-        rc = ensure(c, c->dWavePools, (size_t)plan.grid * stride * RZ_GPOOL_FIELDS * sizeof(unsigned));
-        if (rc != RZ_OK) return rc;
         const size_t claimFloats = (size_t)plan.claimUnits * 384;
-        rc = ensure(c, c->dDeferAdd, (size_t)plan.nClaims * claimFloats * sizeof(float));
-        if (rc != RZ_OK) return rc;
-        rc = ensure(c, c->dDeferFlags, (size_t)plan.nClaims * sizeof(int32_t));
-        if (rc != RZ_OK) return rc;
-        K.wpool = static_cast<unsigned*>(c->dWavePools.p);
-        K.wpoolStride = (uint32_t)stride;
-        K.wpoolChunk = (uint32_t)chunk;
-        K.daddends = static_cast<float*>(c->dDeferAdd.p);
-        K.dflags = static_cast<int32_t*>(c->dDeferFlags.p);
-        K.dClaimStride = (uint32_t)claimFloats;
+        const char* forceNo = std::getenv("RZ_DEBUG_NO_POOL_MEMORY");      // test aid: as if the device had no room for it
+        if (!(forceNo && std::atoi(forceNo) != 0) &&
+            ensure_optional(c->dWavePools, (size_t)plan.grid * stride * RZ_GPOOL_FIELDS * sizeof(unsigned)) &&
+            ensure_optional(c->dDeferAdd, (size_t)plan.nClaims * claimFloats * sizeof(float)) &&
+            ensure_optional(c->dDeferFlags, (size_t)plan.nClaims * sizeof(int32_t))) {
+            K.wpool = static_cast<unsigned*>(c->dWavePools.p);
+            K.wpoolStride = (uint32_t)stride;
+            K.wpoolChunk = (uint32_t)chunk;
+            K.daddends = static_cast<float*>(c->dDeferAdd.p);
+            K.dflags = static_cast<int32_t*>(c->dDeferFlags.p);
+            K.dClaimStride = (uint32_t)claimFloats;
+        }
     }
     c->lastGlobalPool = K.wpool != nullptr;
     RZ_HIP(c, hipEventRecord(c->evStart[evSlot], c->stream));

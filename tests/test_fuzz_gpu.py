@@ -124,3 +124,27 @@ def test_random_opaque_scene_through_claims_and_cross_claim_pools(seed, monkeypa
     assert name == "rz_render_samples+pool", name
     ref = oracle_render(sc, W, H, spp, b, nthreads=16)
     assert (gpu.view(np.uint32) == ref.view(np.uint32)).all(), f"seed {seed} ({W}x{H}, {spp} spp, {b} bounces, claims of {per_claim}): " + mismatch_report(gpu, ref)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_a_launch_that_gets_no_memory_for_its_cross_claim_pools_renders_the_same_frame(seed, monkeypatch):
+    """The pools' scratch (1.5 KB per unit of the launch) is optional: a launch that cannot have it -- here: is told so -- lets
+    every claim work its parked paths off by itself, and the frame is the same."""
+    sc, rng = random_scene(7000 + seed, opaque=True)
+    W, H, spp, b = 128, 72, int(rng.choice([16, 64, 100])), 5
+    sc.camera.aspect = W / H
+    sc.camera.update()
+    monkeypatch.setenv("RZ_GROUPS_PER_CLAIM", "8")
+    monkeypatch.setenv("RZ_CROSS_CLAIM_POOL", "1")
+    from rayzen_amd.renderer import Renderer
+    frames, names = [], []
+    for no_memory in ("0", "1"):
+        monkeypatch.setenv("RZ_DEBUG_NO_POOL_MEMORY", no_memory)
+        r = Renderer(0)
+        frames.append(hip_render(sc, W, H, spp, b, renderer=r))
+        names.append(r.last_kernel_name())
+        r.close()
+    assert names == ["rz_render_samples+pool", "rz_render_samples"], names
+    ref = oracle_render(sc, W, H, spp, b, nthreads=16)
+    for f in frames:
+        assert (f.view(np.uint32) == ref.view(np.uint32)).all(), f"seed {seed}: " + mismatch_report(f, ref)
