@@ -350,14 +350,39 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
                 //  node numbers does what comparing the 64-bit addresses did, and the address is computed on the scalar unit)
                 const int ucur = MI ? 0 : __builtin_amdgcn_readfirstlane(cur);
                 if (!MI && rz_ballot(cur != ucur) == 0ull) {     // every active lane wants the same pair: one scalar fetch,
-                    RZ_SITE(c, 7);                        // box values consumed straight from SGPRs
-                    const f32x16 q = sload16_off(pairs, (unsigned)ucur << 6);     // (a BLAS's pairs span < 4 GiB: rz_context.hip, finalize)
-                    const f32x2 lx = {q[0], q[1]}, ly = {q[2], q[3]}, lz = {q[4], q[5]};
-                    const f32x2 rx = {q[6], q[7]}, ry = {q[8], q[9]}, rz = {q[10], q[11]};
+                    // box values consumed straight from SGPRs.  And while the lanes also AGREE on where to go -- the samples of a
+                    // pixel nearly always do -- the walk stays on the scalar unit: the cursor is an SGPR, the decision two ballots
+                    // and a compare, and none of the per-lane selects, exec masks and the uniformity test of the general step are
+                    // executed (they were half of a step's 61 instructions).  Same pushes, same culls, same order per lane.
+                    int u = ucur, lenc, renc;
+                    const unsigned long long ex = rz_ballot(true);
                     float tl, tr;
-                    bool hl, hr;
-                    RZ_SLAB_PAIR(OCT, RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
-                    step(hl, tl, hr, tr, __float_as_int(q[12]), __float_as_int(q[13]));
+                    bool hl, hr, mixed;
+                    int steps = 0;
+                    do {
+                        RZ_SITE(c, 7);
+                        if (COUNT && steps > 0) c.blas_nodes += 2;
+                        ++steps;
+                        const f32x16 q = sload16_off(pairs, (unsigned)u << 6);     // (a BLAS's pairs span < 4 GiB: rz_context.hip, finalize)
+                        const f32x2 lx = {q[0], q[1]}, ly = {q[2], q[3]}, lz = {q[4], q[5]};
+                        const f32x2 rx = {q[6], q[7]}, ry = {q[8], q[9]}, rz = {q[10], q[11]};
+                        RZ_SLAB_PAIR(OCT, RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
+                        lenc = __float_as_int(q[12]); renc = __float_as_int(q[13]);
+                        // (lane masks combined as integers: a ballot of `hr && !(tr > tLoc)` is materialised per lane and compared again)
+                        const unsigned long long mHl = rz_ballot(hl);
+                        const unsigned long long mR = rz_ballot(hr) & ~rz_ballot(tr > tLoc);
+                        mixed = true;
+                        if (mR == ex) {                 // everybody goes on into the right child; a hit left child waits on the lane's stack
+                            if (mHl != 0ull) {
+                                if (in_mask(mHl)) push_entry(bstk, sp, make_uint2((unsigned)lenc, __float_as_uint(tl)));
+                            }
+                            u = renc; mixed = false;
+                        } else if (mR == 0ull && (mHl & ~rz_ballot(tl > tLoc)) == ex) {     // nobody does, and everybody enters the left child directly
+                            u = lenc; mixed = false;
+                        }
+                    } while (!mixed && u >= 0);
+                    if (mixed) step(hl, tl, hr, tr, lenc, renc);    // the lanes part ways here: the general step, on the pair just tested
+                    else cur = u;
                 } else
 #endif
                 {
