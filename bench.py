@@ -67,61 +67,12 @@ def mix_model(pj, kernel_s, clock_hz):
                     "the SIMDs busy for this fraction of the kernel's duration; a model, not a counter"}
 
 
-# ---- work model (the table is DESIGN.md section 4.7) ------------------------------------------------
-# The issue fraction above rises when a kernel executes MORE instructions; it cannot compare designs.  This one prices what
-# the reference ALGORITHM needs for the frame that was rendered -- the units rz_render_counted tallies for THIS launch, the
-# same ones SURVEY 8(d) prices in bytes -- in f32 lane-operations: one per add / subtract / multiply / compare / min / max of
-# the shader as written (no FMA), a reciprocal at its shortest proven correctly-rounded form (v_rcp + one Newton step = 3), a
-# quotient by Markstein's correction on that reciprocal (3 + 3, three more per further quotient by the same divisor), a
-# square root at v_sqrt + one residual step (5), a binary64 operation of the pinned sin / cos / acos at 2.  It falls only when
-# work is removed or the frame gets slower; nothing about the kernel's own instruction stream enters it.
-LANE_PEAK = SIMDS * 32 * MAX_CLOCK_HZ           # useful lane-operations per second: every SIMD retires 32 lanes per cycle
-RCP, DIV, DIV_MORE, SQRT = 3, 6, 3, 5
-NORMALIZE = 5 + SQRT + RCP + 3 * DIV_MORE       # dot, sqrt, three quotients by one divisor (the pinned v / sqrt(dot(v, v)))
-WORK_OPS = {
-    # FS:380-388 + the cull of FS:430 / 468: 6 subtract, 6 multiply, 6 min/max per axis pair, 2 + 2 to combine, max(tmin, 0), 2 compares
-    "box_test": 25,
-    # FS:391-416 with the edges laid out once (DevTri): cross 9, dot 5, |a| test 1, 1/a, s 3, u 6 + 2 compares, cross 9, v 6 + add + 2
-    # compares, t 6 + compare, t < tHit
-    "triangle_test": 9 + 5 + 1 + RCP + 3 + 6 + 2 + 9 + 6 + 3 + 6 + 1 + 1,
-    # FS:473-478: origin (9 mul + 9 add) and direction (9 + 6) into the instance's space, normalize, 1 / direction
-    "instance_entry": 18 + 15 + NORMALIZE + 3 * RCP,
-    # per closest-hit query: 1 / direction in world space (FS:463)
-    "query": 3 * RCP,
-    # per query that found something: FS:410, 484-486 once (6 + 18 + length 3 + 5 + SQRT + compare) and the winner's normal, FS:489-491 (15 + normalize)
-    "query_hit": 6 + 18 + 3 + 5 + SQRT + 1 + 15 + NORMALIZE,
-    # per (lit point, light): FS:578-588 / 622-635 set-up (to-light vector 3, length 5 + SQRT, max, normalize, offset 6) and the
-    # GGX / Schlick / Lambert term of FS:636-659 (two normalize + 3 adds, three dots + max, Fresnel 13, D 8 + DIV, k 3 + DIV, G 2 x (3 + DIV)
-    # + 1, denominator 3, specular 6 + DIV + 2 DIV_MORE, diffuse 9 + DIV + 2 DIV_MORE, sum and scale 15, attenuation 2 + DIV)
-    "light": (3 + 5 + SQRT + 1 + NORMALIZE + 6) + (2 * NORMALIZE + 6 + 18 + 13 + 8 + DIV + 3 + DIV + 2 * (3 + DIV) + 1 + 3
-                                                   + 6 + DIV + 2 * DIV_MORE + 9 + DIV + 2 * DIV_MORE + 15 + 2 + DIV),
-    # per scatter (FS:720-769): the hash number (dot 3, binary64 sine ~30 ops, fract 3), the tangent frame and the combination of
-    # FS:196-201 (two cross 18, three normalize, 15), offset and roulette 12; from the second scatter on also two more hash numbers,
-    # acos (~40 binary64 ops) and two sine / cosine pairs (~60 each) -- the first scatter's local direction is a constant (tempseed = 0)
-    "scatter_first": (3 + 2 * 30 + 3) + 18 + 3 * NORMALIZE + 15 + 12,
-    "scatter_later": (3 + 2 * 30 + 3) + 18 + 3 * NORMALIZE + 15 + 12 + 2 * (3 + 2 * 30 + 3) + 2 * 40 + 2 * 2 * 60,
-}
-
-
-def work_model(counters, n_lights, kernel_s):
-    """Algorithmic lane-operations of the counted launch / what the chip's SIMDs could retire in the kernel's duration."""
-    c = counters
-    nl = max(1, n_lights)
-    primary_hits = c["light_fetches"] // nl                    # lighting runs once per primary hit and fetches every light
-    # segment queries = all queries - shadow queries (one per light fetch in an opaque scene); the ones that hit something
-    # scatter.  The counted launch does not split `materials` into scatter and shadow hits, so the later scatters are bounded
-    # by the segment queries after the primary one (an upper bound: it prices a miss as a scatter).
-    later = max(0, c["traversals"] - c["light_fetches"] - c["samples"])
-    units = {"box_test": c["blas_nodes"] + c["tlas_nodes"], "triangle_test": c["triangles"], "instance_entry": c["instances"],
-             "query": c["traversals"], "query_hit": c["materials"], "light": c["light_fetches"],
-             "scatter_first": primary_hits, "scatter_later": min(later, c["materials"])}
-    ops = {k: units[k] * WORK_OPS[k] for k in units}
-    total = sum(ops.values())
-    return {"lane_ops": int(total), "peak_lane_ops_per_s": LANE_PEAK, "frac": round(total / kernel_s / LANE_PEAK, 4),
-            "traversal_share": round((ops["box_test"] + ops["triangle_test"]) / total, 3),
-            "ops_per_unit": WORK_OPS, "units": {k: int(v) for k, v in units.items()},
-            "note": "algorithmic f32 lane-operations of THIS launch (rz_render_counted's tallies x the table of DESIGN.md 4.7) / (kernel "
-                    "duration x 1024 SIMDs x 32 lanes x 2.4 GHz): falls only when work is removed or the frame gets slower"}
+# ---- work model (rayzen_amd/workmodel.py) ----------------------------------------------------------
+# The issue fraction above rises when a kernel executes MORE instructions; it cannot compare designs.  The work model prices
+# what the reference ALGORITHM needs for the frame that was rendered -- the units rz_render_counted tallies for THIS launch -- as
+# a FLOOR of VALU issue slots per lane (every instruction one slot, best known bit-exact forms), so that it can never exceed
+# what the kernel executed on live lanes; it rises only when the frame gets faster.
+from rayzen_amd.workmodel import LANE_PEAK, executed_live_lane_valu, work_model      # noqa: E402
 
 
 INST_COUNTERS = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
@@ -241,7 +192,21 @@ def main(argv=None):
                 print(f"[bench] rz_group_unique_id failed ({e}); falling back to torch.distributed.reduce", file=sys.stderr)
         dist.broadcast(uid, 0)
         if int(ok.item()) == 1 and int(uid[128].item()) == 1:
-            group = rzdist.Group.create_rank(dev_index, rank, world, bytes(uid[:128].cpu().numpy().tobytes()), flags)
+            # (3) join -- and agree on the OUTCOME too: a rank whose rz_group_create_rank fails after the
+            # communicator's rendezvous (or on every rank alike) must not leave the others rendering into a group it is not in
+            made = torch.ones(1, dtype=torch.int32, device=dev)
+            try:
+                group = rzdist.Group.create_rank(dev_index, rank, world, bytes(uid[:128].cpu().numpy().tobytes()), flags)
+            except Exception as e:
+                print(f"[bench] rank {rank}: rz_group_create_rank failed ({e}); falling back to torch.distributed.reduce", file=sys.stderr)
+                group = None
+                made.zero_()
+            dist.all_reduce(made, op=dist.ReduceOp.MIN)
+            if int(made.item()) != 1:
+                if group is not None:
+                    group.close()
+                    group = None
+                use_group = False
         else:
             use_group = False
     if group is not None:
@@ -380,7 +345,8 @@ def main(argv=None):
                "note": "algorithmic bytes = what RayZen's shader would read from its SSBOs for this frame (SURVEY 8d), counted "
                        "exactly by the instrumented launch; the 6 MB scene is cache resident, so this exceeds the HBM peak and "
                        "bounds nothing -- the counter traffic below is what HBM actually moved"}
-        wm = work_model(counters, len(sc.lights), kernel_s)
+        # (one process driving N devices: `counters` is the sum over the members, so the lane slots on offer are N chips')
+        wm = work_model(counters, kernel_s, n_chips=len(members))
         roof = {"bound": "inst-issue", "achieved": None, "peak": round(ISSUE_PEAK_GINST, 1), "unit": "Gwave-inst/s", "frac": None,
                 "traffic": None, "kernel": r.last_kernel_name(), "kernel_ms": round(kms, 3), "hbm": hbm,
                 "peak_note": f"{SIMDS} SIMDs x {MAX_CLOCK_HZ / 1e9} GHz / {ISSUE_CYCLES_PER_INST} cycles per wave64 instruction "
@@ -408,6 +374,7 @@ def main(argv=None):
                                  # what share of the issue slots did VALU work on live lanes: VALU share of the instructions x lane utilisation x issue fraction
                                  "useful_lane_frac": round(pj["SQ_INSTS_VALU"] / kernel_s / 1e9 / ISSUE_PEAK_GINST
                                                            * pj["SQ_THREAD_CYCLES_VALU"] / (64.0 * pj["SQ_ACTIVE_INST_VALU"]), 4),
+                                 "executed_live_lane_valu": int(executed_live_lane_valu(pj)),
                                  "counters_from": os.path.relpath(PMC_JSON, ROOT), "counters_source_hash": src_hash[:16]})
                     # in-kernel clock under this load: GRBM_GUI_ACTIVE (sum over 8 XCDs) / 8 / the profiled duration
                     clk = 2.39e9
@@ -426,6 +393,10 @@ def main(argv=None):
             except Exception as e:      # a malformed profile must not take the benchmark down
                 roof["counters_stale"] = f"cannot read {PMC_JSON}: {e}"
         roof["work_model"] = wm
+        if "executed_live_lane_valu" in roof:
+            # the floor must lie below what the kernel executed on live lanes -- or the table over-prices a unit
+            wm["floor_over_executed"] = round(wm["lane_slots"] / max(roof["executed_live_lane_valu"], 1), 4)
+            assert wm["lane_slots"] <= roof["executed_live_lane_valu"], (wm["lane_slots"], roof["executed_live_lane_valu"])
         out["roofline"] = roof
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import rzo

@@ -143,6 +143,12 @@ typedef struct rz_counters {
     uint64_t materials;         /* materials[] fetches                       */
     uint64_t light_fetches;     /* lights[] fetches                          */
     uint64_t pixels;            /* accumulation-buffer pixels written        */
+    /* units of the shading side (round 4: the work model of bench.py prices them instead of bounding them) */
+    uint64_t scatters;          /* FS:720-761 executed (a segment that hit)   */
+    uint64_t diffuse_scatters;  /* ... of them through FS:755 (hemisphere)    */
+    uint64_t hemi_draws;        /* ... of those with a non-zero seed (FS:193-195 evaluated; bounce 0 draws a constant) */
+    uint64_t lit_lights;        /* (point, light) pairs whose BRDF term was evaluated (FS:589-607 / 636-659) */
+    uint64_t triangles_past_u;  /* hitTriangle calls that pass FS:396-401 (|a|, u range) and run the second half */
 } rz_counters;
 
 typedef struct rz_ctx rz_ctx;
@@ -172,10 +178,13 @@ int rz_update(rz_ctx* ctx, rz_binding binding, size_t offset,
  * (n x 16 floats, column-major, n == number of uploaded instances); the library inverts them, recomputes the world
  * AABBs (main.cpp:1168-1191) and rebuilds the TLAS (BVH.cpp:178-240) in one small kernel.  The result is byte-identical
  * to what the host library (SceneBuffers::updateDynamic, librayzen_host.so) produces and rz_read_binding returns it.
- * Against a real RayZen build the TLAS topology is the same algorithm, but inverses and world boxes may differ by ulps:
- * RayZen computes them with GLM (glm::inverse, mat4 * vec4), whose evaluation order is not reproduced here (GLM is not
- * vendored with the reference).  Synchronises the context's stream (the TLAS depth sizes the next
- * launch). */
+ * Inverses and world boxes follow GLM 0.9.9's evaluation order, which is what RayZen's own code executes at
+ * main.cpp:974-1001 and 1150-1191: glm::inverse = compute_inverse<4, 4> (the eighteen 2x2 sub-determinants, cofactor
+ * columns with alternating signs, the determinant from the cofactors' first row summed pairwise, every cofactor times
+ * its reciprocal) and mat4 * vec4 = (m0 x + m1 y) + (m2 z + m3 w).  GLM is not vendored with the reference and is absent
+ * from this image, so this is a RESTATEMENT of its published algorithm (rz_linalg.h on the host, rz_tlas_device.hip on
+ * the device; the CPU checker states it a third time), pinned by hand-derived known answers in tests/test_linalg_glm.py -- not a run of
+ * GLM.  Synchronises the context's stream (the TLAS depth sizes the next launch). */
 int rz_update_transforms(rz_ctx* ctx, const float* transforms, size_t n);
 
 /* BVH::buildBLAS (RayZen/src/BVH.cpp:99-175 with the full-sweep SAH of :22-97; called per mesh from main.cpp:954-958)

@@ -91,7 +91,7 @@ static inline int intersect_aabb(v3 o, v3 invd, const float* bmin, const float* 
 }
 
 /* FS:391-416 */
-static inline int hit_triangle(const rzo_triangle* tri, v3 o, v3 d, float* tHit, v3* hp, v3* n, int* mat) {
+static inline int hit_triangle(const rzo_triangle* tri, v3 o, v3 d, float* tHit, v3* hp, v3* n, int* mat, uint64_t* pastU) {
     v3 v0 = ld3(tri->v0);
     v3 edge1 = sub3(ld3(tri->v1), v0);
     v3 edge2 = sub3(ld3(tri->v2), v0);
@@ -102,6 +102,7 @@ static inline int hit_triangle(const rzo_triangle* tri, v3 o, v3 d, float* tHit,
     v3 s = sub3(o, v0);
     float u = f * dot3(s, h);
     if (u < 0.0f || u > 1.0f) return 0;
+    ++*pastU;                                   /* (tally: tests that reach FS:403, the second half of the test) */
     v3 q = cross3(s, edge1);
     float v = f * dot3(d, q);
     if (v < 0.0f || u + v > 1.0f) return 0;
@@ -160,7 +161,7 @@ static int traverse_blas(rctx* c, v3 o, v3 d, int nodeOff, int triOff, int gTriO
                 int triIdx = gTriOff + sc->blas_indices[triOff + node->leftFirst + i];
                 c->cnt.triangles++;
                 float t; v3 thp = V3(0, 0, 0), tn = V3(0, 0, 0); int tm = -1;
-                if (hit_triangle(&sc->triangles[triIdx], o, d, &t, &thp, &tn, &tm)) {
+                if (hit_triangle(&sc->triangles[triIdx], o, d, &t, &thp, &tn, &tm, &c->cnt.triangles_past_u)) {
                     if (t < tHit) { tHit = t; *hpOut = thp; *nOut = tn; *matOut = tm; hit = 1; }
                 }
             }
@@ -299,6 +300,7 @@ static v3 calculate_lighting(rctx* c, int numLights, v3 hitPoint, v3 normal, con
                 if (!shadow_visibility(c, add3(hitPoint, scale3(L, 0.001f)), L, 1e30f, &visibility)) continue;
             }
             attenuation *= visibility;
+            c->cnt.lit_lights++;
             float NdotL = rzo_max(dot3(normal, L), 0.0f);
             if (NdotL <= 0.0f) continue;
             v3 H = normalize3(add3(L, viewDir));
@@ -347,6 +349,7 @@ static v3 calculate_lighting(rctx* c, int numLights, v3 hitPoint, v3 normal, con
             if (!shadow_visibility(c, add3(hitPoint, scale3(lightDir, 0.001f)), lightDir, 1e30f, &visibility)) continue;
         }
         attenuation *= visibility;
+        c->cnt.lit_lights++;
         v3 halfwayDir = normalize3(add3(lightDir, viewDir));
         float NdotL = rzo_max(dot3(normal, lightDir), 0.0f);
         float NdotV = rzo_max(dot3(normal, viewDir), 0.0f);
@@ -428,6 +431,7 @@ static void shade_pixel(rctx* c, const rzo_frame* fr, int px, int py, float* acc
             }
             v2 rs = {tempseed.x + (float)samp, tempseed.y + (float)bounce};
             float randVal = rz_rand(rs);
+            c->cnt.scatters++;
             if (hm->transparency > 0.0f) {                                  /* FS:723-747 */
                 int entering = dot3(neg3(currentDirection), hitNormal) > 0.0f;
                 v3 N = entering ? hitNormal : neg3(hitNormal);
@@ -459,6 +463,8 @@ static void shade_pixel(rctx* c, const rzo_frame* fr, int px, int py, float* acc
                     throughput = scale3(throughput, 0.95f);
                 } else {
                     currentDirection = random_hemisphere_direction(hitNormal, tempseed);
+                    c->cnt.diffuse_scatters++;
+                    if (!(tempseed.x == 0.0f && tempseed.y == 0.0f)) c->cnt.hemi_draws++;   /* (at bounce 0 the seed is (+0, +0) for every sample: FS:696) */
                     throughput = mul3(throughput, scale3(ld3(hm->albedo), 0.4f));
                 }
             }

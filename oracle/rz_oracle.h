@@ -61,7 +61,11 @@ typedef struct {
 
 typedef struct {
     uint64_t samples, traversals, tlas_nodes, tlas_leaf_indices, instances,
-             blas_nodes, triangles, materials, light_fetches, pixels;
+             blas_nodes, triangles, materials, light_fetches, pixels,
+             /* shading-side units (the benchmark's work model prices them): FS:720-761 executed; of them through FS:755; of
+              * those with a non-zero seed (FS:193-195 really evaluated); (point, light) pairs whose BRDF term was evaluated */
+             scatters, diffuse_scatters, hemi_draws, lit_lights,
+             triangles_past_u;      /* hitTriangle calls that pass the |a| and u-range tests (FS:396-401) and run its second half */
 } rzo_counters;
 
 /* Render pixels [x0,x1) x [y0,y1) (row 0 = bottom row, gl_FragCoord origin)

@@ -25,7 +25,8 @@ LIGHT = np.dtype([("posdir", "<f4", 4), ("color", "<f4", 3), ("power", "<f4")])
 assert (TRIANGLE.itemsize, NODE.itemsize, INSTANCE.itemsize, MATERIAL.itemsize, LIGHT.itemsize) == (64, 32, 144, 32, 32)
 
 COUNTER_FIELDS = ("samples", "traversals", "tlas_nodes", "tlas_leaf_indices", "instances",
-                  "blas_nodes", "triangles", "materials", "light_fetches", "pixels")
+                  "blas_nodes", "triangles", "materials", "light_fetches", "pixels",
+                  "scatters", "diffuse_scatters", "hemi_draws", "lit_lights", "triangles_past_u")
 
 
 class _Scene(C.Structure):

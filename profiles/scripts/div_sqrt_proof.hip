@@ -5,7 +5,8 @@
 //     (Markstein's correction; correctly rounded by his theorem when q0 is within an ulp of a / b, which RN(a RN(1/b)) is not
 //     PROVEN to be -- hence the sweep): 2^33 random operand pairs, every mantissa of b against 64 numerators, every mantissa of a
 //     against 64 divisors, and the exponent boundaries of the admitted range.  Not exhaustive (2^64 pairs): a measured claim.
-// The PRODUCT lines check rz_device_math.h's own functions under their own admission tests; tests/test_div_sqrt_gpu.py
+// The PRODUCT lines check rz_device_math.h's own functions under their own admission tests (the three-numerator test of div3 /
+// normalize included: its admitted set is compared with the scalar one pattern by pattern); tests/test_div_sqrt_gpu.py
 // builds and runs this file on the GPU of the test run and asserts on them.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I rayzen_amd/csrc/hip -I include -o /tmp/div_sqrt_proof profiles/scripts/div_sqrt_proof.hip
 #include <hip/hip_runtime.h>
@@ -109,6 +110,40 @@ __global__ void sweep_div_product(unsigned long long* out, unsigned long long n,
     atomicAdd(&out[0], admitted); atomicAdd(&out[1], bad); atomicAdd(&out[2], rejected);
 }
 
+// The admission test the product SHIPS for three numerators at once (div3, normalize): (1) for every one of the 2^32 bit patterns
+// v, in each of the three positions beside two harmless components, div_mid_num3_ok agrees with div_mid_num_ok(v) -- the admitted
+// sets are equal (round 3's version admitted positive magnitudes below 2^-60: ADVICE r3); (2) random vectors with components over
+// the WHOLE range (zeros of both signs, denormals, infinities, NaNs): whatever num3_ok admits, div_mid divides correctly.
+__global__ void sweep_num3_sets(unsigned long long* out) {            // out[0] patterns tried, out[1] disagreements, out[2] admitted
+    unsigned long long bad = 0, adm = 0, tried = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += (unsigned long long)gridDim.x * blockDim.x) {
+        const float v = __uint_as_float((unsigned)i);
+        const bool one = rz::div_mid_num_ok(v);
+        const bool x = rz::div_mid_num3_ok(rz::mk3(v, 1.0f, -3.5f)), y = rz::div_mid_num3_ok(rz::mk3(0.0f, v, 0x1p-60f)), z = rz::div_mid_num3_ok(rz::mk3(0x1p60f, -1.0f, v));
+        ++tried; adm += one ? 1 : 0;
+        if (x != one || y != one || z != one) ++bad;
+    }
+    atomicAdd(&out[0], tried); atomicAdd(&out[1], bad); atomicAdd(&out[2], adm);
+}
+__global__ void sweep_div3_product(unsigned long long* out, unsigned long long n, unsigned long long seed) {     // out[0] admitted vectors, out[1] mismatching components, out[2] rejected
+    unsigned long long admitted = 0, bad = 0, rejected = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        float c[3];
+        for (int k = 0; k < 3; ++k) {
+            const unsigned long long z = mix(seed + 4 * i + k);
+            const unsigned sel = (unsigned)(z >> 56) & 7u;         // a third of the components from the edges of the admitted set
+            c[k] = sel == 0 ? 0.0f : sel == 1 ? -0.0f : sel == 2 ? operand(z, 0, 70) : operand(z, 60, 194);
+        }
+        const float b = operand(mix(seed + 4 * i + 3), 60, 194);
+        const rz::v3 a = rz::mk3(c[0], c[1], c[2]);
+        if (!(rz::div_mid_num3_ok(a) && rz::div_mid_den_ok(b))) { ++rejected; continue; }
+        ++admitted;
+        const float r = rz::rcp_mid(b);
+        for (int k = 0; k < 3; ++k) if (__float_as_uint(c[k] / b) != __float_as_uint(rz::div_mid(c[k], b, r))) ++bad;
+    }
+    atomicAdd(&out[0], admitted); atomicAdd(&out[1], bad); atomicAdd(&out[2], rejected);
+}
+
 int main(int argc, char** argv) {
     const unsigned long long nRandom = argc > 1 ? strtoull(argv[1], nullptr, 0) : (1ull << 33);
     Res* d; hipMalloc(&d, sizeof(Res));
@@ -143,5 +178,11 @@ int main(int argc, char** argv) {
     hipMemset(d2, 0, 24); sweep_div_product<<<8192, 256>>>(d2, nRandom, 5551212ull); hipDeviceSynchronize(); hipMemcpy(h2, d2, 24, hipMemcpyDeviceToHost);
     printf("PRODUCT div_mid: admitted %llu pairs (rejected %llu), mismatches %llu\n", h2[0], h2[2], h2[1]);
     const bool divOk = h2[1] == 0 && h2[0] > nRandom / 16;
-    return sqrtOk && divOk ? 0 : 1;
+    hipMemset(d2, 0, 24); sweep_num3_sets<<<8192, 256>>>(d2); hipDeviceSynchronize(); hipMemcpy(h2, d2, 24, hipMemcpyDeviceToHost);
+    printf("PRODUCT div_mid_num3_ok vs div_mid_num_ok: %llu bit patterns x 3 positions (admitted %llu), disagreements %llu\n", h2[0], h2[2], h2[1]);
+    const bool setsOk = h2[1] == 0 && h2[0] == (1ull << 32);
+    hipMemset(d2, 0, 24); sweep_div3_product<<<8192, 256>>>(d2, nRandom >> 2, 8675309ull); hipDeviceSynchronize(); hipMemcpy(h2, d2, 24, hipMemcpyDeviceToHost);
+    printf("PRODUCT div3 admission: admitted %llu vectors (rejected %llu), mismatches %llu\n", h2[0], h2[2], h2[1]);
+    const bool div3Ok = h2[1] == 0 && h2[0] > nRandom / 256;
+    return sqrtOk && divOk && setsOk && div3Ok ? 0 : 1;
 }

@@ -45,7 +45,8 @@ class FrameParams(C.Structure):
 
 
 COUNTER_FIELDS = ("samples", "traversals", "tlas_nodes", "tlas_leaf_indices", "instances",
-                  "blas_nodes", "triangles", "materials", "light_fetches", "pixels")
+                  "blas_nodes", "triangles", "materials", "light_fetches", "pixels",
+                  "scatters", "diffuse_scatters", "hemi_draws", "lit_lights", "triangles_past_u")
 
 
 class PresentParams(C.Structure):

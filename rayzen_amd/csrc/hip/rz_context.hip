@@ -803,6 +803,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
         out->tlas_leaf_indices = h.tlas_leaf_indices; out->instances = h.instances; out->blas_nodes = h.blas_nodes;
         out->triangles = h.triangles; out->materials = h.materials; out->light_fetches = h.light_fetches;
         out->pixels = h.pixels;
+        out->scatters = h.scatters; out->diffuse_scatters = h.diffuse_scatters; out->hemi_draws = h.hemi_draws; out->lit_lights = h.lit_lights; out->triangles_past_u = h.triangles_past_u;
 #ifdef RZ_PROF
         unsigned long long pr[128];
         RZ_HIP(c, hipMemcpy(pr, static_cast<char*>(c->dCounters.p) + sizeof(DevCounters), sizeof pr, hipMemcpyDeviceToHost));

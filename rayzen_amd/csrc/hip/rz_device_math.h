@@ -127,12 +127,20 @@ __device__ __forceinline__ float sqrt_mid(float x) {
     return __builtin_fmaf(e, h, s);
 }
 
-// Three numerators at once: +0, or magnitude within [2^-60, 2^60] -- the per-component test folded into integer min / max
-// (min(|bits| - lo, bits) is 0 for +0, stays out of range for -0) and ONE compare.
+// Three numerators at once, the SAME admitted set as div_mid_num_ok per component: +0, or magnitude within [2^-60, 2^60].
+// Two folded integer tests: (1) min(|bits| - lo, bits) is 0 for +0, stays out of range for -0 and for everything above the
+// range -- but a POSITIVE magnitude below 2^-60 (denormals included) wraps high in the first operand and is let through by
+// the second (round 3 shipped this test alone: ADVICE r3; for such numerators the residual fma(-q0, b, a) is no longer exact
+// and div_mid misses the IEEE quotient); (2) min3(|bits| - 1) >= lo - 1 holds iff no component has 0 < |bits| < lo (zero
+// wraps to the top).  profiles/scripts/div_sqrt_proof.hip compares this predicate with div_mid_num_ok on every exponent,
+// both signs, zeros, denormals, infinities and NaNs, and drives div3 / normalize themselves.
 __device__ __forceinline__ bool div_mid_num3_ok(v3 a) {
     const unsigned rx = __float_as_uint(a.x), ry = __float_as_uint(a.y), rz = __float_as_uint(a.z);
-    const unsigned tx = min((rx & 0x7fffffffu) - RZ_F32_2M60, rx), ty = min((ry & 0x7fffffffu) - RZ_F32_2M60, ry), tz = min((rz & 0x7fffffffu) - RZ_F32_2M60, rz);
-    return max(max(tx, ty), tz) <= RZ_F32_2P60 - RZ_F32_2M60;
+    const unsigned ax = rx & 0x7fffffffu, ay = ry & 0x7fffffffu, az = rz & 0x7fffffffu;
+    const unsigned tx = min(ax - RZ_F32_2M60, rx), ty = min(ay - RZ_F32_2M60, ry), tz = min(az - RZ_F32_2M60, rz);
+    const bool inOrZero = max(max(tx, ty), tz) <= RZ_F32_2P60 - RZ_F32_2M60;
+    const bool noTiny = min(min(ax - 1u, ay - 1u), az - 1u) >= RZ_F32_2M60 - 1u;
+    return inOrZero & noTiny;
 }
 // (a.x, a.y, a.z) / b, each the correctly rounded quotient: one reciprocal and three correction steps when the wave's operands
 // are all in range, three IEEE divisions otherwise.

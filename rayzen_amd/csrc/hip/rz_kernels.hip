@@ -126,6 +126,11 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void r
         atomicAdd(&g->triangles, (unsigned long long)c.triangles);
         atomicAdd(&g->materials, (unsigned long long)c.materials);
         atomicAdd(&g->light_fetches, (unsigned long long)c.light_fetches);
+        atomicAdd(&g->scatters, (unsigned long long)c.scatters);
+        atomicAdd(&g->diffuse_scatters, (unsigned long long)c.diffuse_scatters);
+        atomicAdd(&g->hemi_draws, (unsigned long long)c.hemi_draws);
+        atomicAdd(&g->lit_lights, (unsigned long long)c.lit_lights);
+        atomicAdd(&g->triangles_past_u, (unsigned long long)c.triangles_past_u);
         if (inside) atomicAdd(&g->pixels, 1ull);
     }
 }
@@ -183,11 +188,25 @@ __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
     a.traversals += b.traversals; a.tlas_nodes += b.tlas_nodes; a.tlas_leaf_indices += b.tlas_leaf_indices;
     a.instances += b.instances; a.blas_nodes += b.blas_nodes; a.triangles += b.triangles; a.materials += b.materials;
     a.light_fetches += b.light_fetches; a.samples += b.samples;
+    a.triangles_past_u += b.triangles_past_u; a.scatters += b.scatters; a.diffuse_scatters += b.diffuse_scatters; a.hemi_draws += b.hemi_draws; a.lit_lights += b.lit_lights;
 #ifdef RZ_PROF
     for (int k = 0; k < 16; ++k) a.p[k] += b.p[k];
     for (int k = 0; k < 16; ++k) a.t[k] += b.t[k];
     for (int r = 0; r < 8; ++r) { a.rt[r] += b.rt[r]; for (int k = 0; k < 10; ++k) a.rp[r][k] += b.rp[r][k]; }
 #endif
+}
+
+// A wave's tallies to the launch's counters (the counting instantiations only): one atomic per counter per wave, reduced across
+// the lanes first.  DevCounters is an array of 64-bit words in this order; `pixels` (word 9) is added by the code that stores pixels.
+__device__ __forceinline__ void tally_flush(const KParams& K, const Tally& c) {
+    const unsigned v[14] = {c.samples, c.traversals, c.tlas_nodes, c.tlas_leaf_indices, c.instances, c.blas_nodes,
+                            c.triangles, c.materials, c.light_fetches, c.scatters, c.diffuse_scatters, c.hemi_draws, c.lit_lights, c.triangles_past_u};
+    unsigned long long* g = reinterpret_cast<unsigned long long*>(K.counters);
+    for (int k = 0; k < 14; ++k) {
+        unsigned x = v[k];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&g[k < 9 ? k : k + 1], (unsigned long long)x);
+    }
 }
 
 // Persistent waves: the grid is RZ_PERSIST_WAVES_PER_CU waves per CU (>= what fits) and each wave claims
@@ -496,15 +515,7 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
     }
 #endif
     if (COUNT) {
-        // one atomic per counter per wave: reduce across lanes first
-        unsigned v[9] = {c.samples, c.traversals, c.tlas_nodes, c.tlas_leaf_indices, c.instances, c.blas_nodes,
-                         c.triangles, c.materials, c.light_fetches};
-        unsigned long long* g = reinterpret_cast<unsigned long long*>(K.counters);
-        for (int k = 0; k < 9; ++k) {
-            unsigned x = v[k];
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-            if (lane == 0 && x) atomicAdd(&g[k], (unsigned long long)x);
-        }
+        tally_flush(K, c);
         const unsigned long long pm = rz_ballot(sumInside);   // lanes 0..pixPerWave-1 (lane 0 alone when spp >= 64)
         if (lane == 0 && pm) atomicAdd(&K.counters->pixels, (unsigned long long)__popcll(pm));
     }
@@ -800,14 +811,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
     __syncthreads();
     if (!claimDeferred) claim_ordered_sums<COUNT>(K, M, ci, addBase, nPix, ppw, nBatches);
     if (COUNT) {
-        unsigned v[9] = {c.samples, c.traversals, c.tlas_nodes, c.tlas_leaf_indices, c.instances, c.blas_nodes,
-                         c.triangles, c.materials, c.light_fetches};
-        unsigned long long* g = reinterpret_cast<unsigned long long*>(K.counters);
-        for (int k = 0; k < 9; ++k) {
-            unsigned x = v[k];
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-            if (lane == 0 && x) atomicAdd(&g[k], (unsigned long long)x);
-        }
+        tally_flush(K, c);
 #ifdef RZ_PROF
         unsigned long long* pr = reinterpret_cast<unsigned long long*>(K.counters + 1);
         for (int k = 0; k < 16; ++k) if (c.p[k]) atomicAdd(&pr[k], (unsigned long long)c.p[k]);
@@ -907,14 +911,7 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
 #endif
     __syncthreads();
     if (COUNT) {
-        unsigned v[9] = {c.samples, c.traversals, c.tlas_nodes, c.tlas_leaf_indices, c.instances, c.blas_nodes,
-                         c.triangles, c.materials, c.light_fetches};
-        unsigned long long* g = reinterpret_cast<unsigned long long*>(K.counters);
-        for (int k = 0; k < 9; ++k) {
-            unsigned x = v[k];
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-            if (lane == 0 && x) atomicAdd(&g[k], (unsigned long long)x);
-        }
+        tally_flush(K, c);
 #ifdef RZ_PROF
         unsigned long long* pr = reinterpret_cast<unsigned long long*>(K.counters + 1);
         for (int k = 0; k < 16; ++k) if (c.p[k]) atomicAdd(&pr[k], (unsigned long long)c.p[k]);

@@ -218,9 +218,10 @@ __device__ __forceinline__ void shade_light(const KParams& K, Path& P) {
 }
 
 // FS:720-769: choose the next direction at the parked surface point and move on.
-template <bool GLASS>
+template <bool COUNT, bool GLASS>
 __device__ __forceinline__ void scatter(const KParams& K, Path& P, Tally& c) {
     RZ_T0();
+    if (COUNT) c.scatters += 1;
     const DevMaterial M = K.materials[P.hmat];
     const float fb2 = (float)(P.bounce * P.bounce), fb = (float)P.bounce;
     v2 tempseed;
@@ -262,6 +263,7 @@ __device__ __forceinline__ void scatter(const KParams& K, Path& P, Tally& c) {
                 const unsigned long long th0_ = __builtin_amdgcn_s_memtime();
 #endif
                 dir = random_hemisphere_direction(K, hitNormal, tempseed);
+                if (COUNT) { c.diffuse_scatters += 1; if (!(__float_as_uint(tempseed.x) == 0u && __float_as_uint(tempseed.y) == 0u)) c.hemi_draws += 1; }
 #ifdef RZ_PROF
                 c.t[8] += __builtin_amdgcn_s_memtime() - th0_;
 #endif
@@ -284,11 +286,11 @@ __device__ __forceinline__ void scatter(const KParams& K, Path& P, Tally& c) {
 }
 
 // Lighting of the parked point is complete (or there are no lights): FS:717, then scatter.
-template <bool GLASS>
+template <bool COUNT, bool GLASS>
 __device__ __forceinline__ void finish_lighting(const KParams& K, Path& P, Tally& c) {
     P.addLight = P.throughput * P.lacc;
     P.color = P.color + P.addLight;
-    scatter<GLASS>(K, P, c);
+    scatter<COUNT, GLASS>(K, P, c);
 }
 
 // Advance a path by the result of the closest-hit query of its current ray.
@@ -314,10 +316,10 @@ __device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, c
                          : mk3(0.05f * M.albedo[0], 0.05f * M.albedo[1], 0.05f * M.albedo[2]);
             P.li = 0;
             if (K.nLights > 0) { start_light<COUNT, GLASS>(K, P, c); return; }
-            finish_lighting<GLASS>(K, P, c);
+            finish_lighting<COUNT, GLASS>(K, P, c);
             return;
         }
-        scatter<GLASS>(K, P, c);
+        scatter<COUNT, GLASS>(K, P, c);
         return;
     }
     // MODE_SHADOW: the body of one iteration of FS:511-526
@@ -339,10 +341,10 @@ __device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, c
         if (P.iter < 32 && P.vis > 0.05f) return;   // next iteration: trace again
         lit = P.vis > 0.05f;                         // FS:527
     }
-    if (lit) { RZ_T0(); shade_light<GLASS>(K, P); RZ_T1(c, 6); }
+    if (lit) { RZ_T0(); if (COUNT) c.lit_lights += 1; shade_light<GLASS>(K, P); RZ_T1(c, 6); }
     P.li += 1;
     if (P.li < K.nLights) { start_light<COUNT, GLASS>(K, P, c); return; }
-    finish_lighting<GLASS>(K, P, c);
+    finish_lighting<COUNT, GLASS>(K, P, c);
 }
 
 }  // namespace rz

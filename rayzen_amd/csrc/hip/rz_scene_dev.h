@@ -87,7 +87,7 @@ struct DevLight { float posdir[4], color[3], power; };
 
 struct DevCounters {
     unsigned long long samples, traversals, tlas_nodes, tlas_leaf_indices, instances, blas_nodes, triangles,
-        materials, light_fetches, pixels;
+        materials, light_fetches, pixels, scatters, diffuse_scatters, hemi_draws, lit_lights, triangles_past_u;
 };
 
 // Everything a render kernel needs, passed by value.

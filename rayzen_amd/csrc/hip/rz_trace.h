@@ -40,6 +40,9 @@ namespace rz {
 struct Tally {          // per-thread counts of the REFERENCE algorithm's memory touches
     unsigned traversals, tlas_nodes, tlas_leaf_indices, instances, blas_nodes, triangles, materials, light_fetches,
         samples;
+    // units of the shading side (bench.py's work model prices them; the oracle tallies the same events):
+    unsigned triangles_past_u;                                      // hitTriangle calls that pass FS:396-401 and run the second half of the test
+    unsigned scatters, diffuse_scatters, hemi_draws, lit_lights;    // FS:720-761 executed | of them FS:755 | of those with a non-zero seed (binary64 acos / sin / cos evaluated) | FS:636-659 / 589-607 evaluated
 #ifdef RZ_PROF          // diagnostic build only: where do the lanes of a wave spend their iterations?
     unsigned p[16];
     int rnd;                    // which closest-hit query of its path this lane is in (0 primary, 1-2 shadow, 3.. bounces), capped at 7
@@ -196,7 +199,7 @@ __device__ __forceinline__ bool slab_finish(f32x2 tx, f32x2 ty, f32x2 tz, float&
 // FS:391-416 without the outputs that are pure functions of (ray, t, triangle).
 // Evaluated without early exits: the accept decision is the conjunction of the
 // shader's tests in order, so values computed past a failed test are never used.
-__device__ __forceinline__ bool moller_trumbore(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float& t) {
+__device__ __forceinline__ bool moller_trumbore(v3 o, v3 d, v3 v0, v3 e1, v3 e2, float& t, bool& pastU) {
     v3 h = cross(d, e2);
     float a = dot(e1, h);
     // FS:398.  A lane whose |a| < 0.0001 fails the shader's first test whatever f is, so only |a| <= 2^126 has to hold
@@ -212,6 +215,7 @@ __device__ __forceinline__ bool moller_trumbore(v3 o, v3 d, v3 v0, v3 e1, v3 e2,
     const bool aSmall = __builtin_fabsf(a) < 0.0001f;
     const bool uLow = u < 0.0f, uHigh = u > 1.0f;
     const bool ok1 = !aSmall && !uLow && !uHigh;
+    pastU = ok1;            // (for the counting instantiations' tally)
 #ifndef RZ_NO_TRI_EARLY_OUT
     // Wave-level early out after the shader's second test: the lanes of a wave are mostly samples of one pixel testing
     // the same triangle with near-identical rays, so they tend to fail together -- and then the second cross product,
@@ -425,7 +429,9 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
                     float4 a = tp[0], b = tp[1], cc = tp[2];
                     RZ_KEEP4(a);
                     float t;
-                    const bool hit = moller_trumbore(lo, ld, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, cc.x), t);
+                    bool pastU;
+                    const bool hit = moller_trumbore(lo, ld, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, cc.x), t, pastU);
+                    if (COUNT && pastU) c.triangles_past_u += 1;
                     if (hit && t < tLoc) { tLoc = t; best = first + i; }
                 }
                 ++i;
@@ -939,7 +945,9 @@ __device__ __forceinline__ void pool_trace(const KParams& K, unsigned* __restric
                         float4 a = tp[0], b = tp[1], cc = tp[2];
                         RZ_KEEP4(a);
                         float t;
-                        const bool hit = moller_trumbore(lo, ld, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, cc.x), t);
+                        bool pastU;
+                        const bool hit = moller_trumbore(lo, ld, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, cc.x), t, pastU);
+                        if (COUNT && pastU) c.triangles_past_u += 1;
                         if (hit && t < tLoc) { tLoc = t; best = first + i; }
                     }
                     ++i;

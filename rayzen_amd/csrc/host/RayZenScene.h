@@ -72,7 +72,8 @@ public:
     // Longest root-to-leaf path, in nodes (root alone = 1).  The render
     // library sizes its LDS traversal stacks from this.
     int depth() const;
-    // BVH.cpp:242-265: size_t count + raw POD, nodes then triIndices.
+    // (BVH::saveToFile / loadFromFile, BVH.cpp:242-265, are dead code in the reference -- never called -- and are
+    //  intentionally not mirrored; the cache formats RayZen does use live in SceneCache.h.)
 };
 
 struct Material {

@@ -320,13 +320,15 @@ def fit_mesh(tris, radius):
 
 
 def bunny_scene(n=76, aspect=16.0 / 9.0, bunny_material=0, floor_material=4, extras=False, radius=2.8, blas_builder=None,
-                obj_path=None):
+                obj_path=None, camera_position=(0.0, 2.5, 10.0)):
     """C2/C3: ~69k-triangle closed mesh over the reference's floor: the procedural 'bunny' stand-in (12*n*n triangles)
     or, with obj_path, a real OBJ (e.g. the Stanford bunny dropped into assets/bunny.obj) read
     with RayZen's loader quirks (Mesh.cpp:6-50) and fitted to the same radius.
 
-    extras adds a glass blob and a mirror cube so every material branch is exercised."""
-    s = Scene(camera=Camera(position=(0.0, 2.5, 10.0), aspect=aspect))
+    extras adds a glass blob and a mirror cube so every material branch is exercised.
+    camera_position: the default frames the whole mesh from 10 units away (64 % of the camera paths see only sky);
+    CLOSE_CAMERA stands 0.9 units outside the mesh, which then covers most of the frame (bench_configs.py: c2close)."""
+    s = Scene(camera=Camera(position=tuple(camera_position), aspect=aspect))
     floor = s.add_mesh(make_cube(floor_material))
     if obj_path:
         mesh = fit_mesh(load_obj(obj_path, bunny_material), radius)
@@ -344,6 +346,9 @@ def bunny_scene(n=76, aspect=16.0 / 9.0, bunny_material=0, floor_material=4, ext
     s.name = (f"obj:{len(mesh)}" if obj_path else f"bunny{12 * n * n}") + ("+glass+mirror" if extras else "")
     s.set_blas_builder(blas_builder)        # a Renderer: BLAS built on the device (same bytes); None: host builder
     return s.build()
+
+
+CLOSE_CAMERA = (0.0, 2.2, 3.7)     # looks down -z like the default camera (RayZen's conventions: main.cpp:331-339)
 
 
 def instanced_transforms(frame, count=16, spacing=3.0, obj_scale=0.4):
@@ -404,3 +409,28 @@ def reference_scene(aspect=800.0 / 600.0, mesh_n=9):
     s.add_object(glass, translate(scale(I, (1.2, 1.2, 1.2)), (2.5, 0.8, 2.5)))
     s.name = f"rayzen-main-scene(7 objects, 12+5x{12 * mesh_n * mesh_n} tris)"
     return s.build()
+
+
+# The named workloads of the measurement scripts (bench_configs.py, profiles/scripts/*): BASELINE.json's configurations on one
+# GPU and their companions.  name -> (scene factory, width, height, spp, bounces).
+NAMED_CONFIGS = {
+    "c1": (lambda: cornell_scene(), 256, 256, 4, 1),
+    "c2": (lambda: bunny_scene(n=76, aspect=16 / 9), 1920, 1080, 64, 4),                     # BASELINE configs[1], the bench workload
+    # ... the same mesh, frame, spp and bounces with the camera 0.9 units outside the mesh: most camera paths hit geometry
+    # (configs[1] fixes size / spp / bounces / triangles, not the camera; at the bench camera 64 % of the paths see only sky)
+    "c2close": (lambda: bunny_scene(n=76, aspect=16 / 9, camera_position=CLOSE_CAMERA), 1920, 1080, 64, 4),
+    "c2g": (lambda: bunny_scene(n=76, aspect=16 / 9, extras=True), 1920, 1080, 64, 4),       # + a glass blob and a mirror cube
+    "glassbunny": (lambda: bunny_scene(n=76, aspect=16 / 9, bunny_material=3), 1920, 1080, 64, 4),
+    "mirror": (lambda: bunny_scene(n=76, aspect=16 / 9, bunny_material=2, floor_material=2), 1920, 1080, 64, 8),
+    "c3": (lambda: bunny_scene(n=76, aspect=16 / 9), 1920, 1080, 256, 4),                    # configs[2]'s frame, whole on one GPU
+    "c4": (lambda: instanced_scene(n=76, count=16, aspect=16 / 9), 1920, 1080, 16, 4),
+    "c5": (lambda: stress_scene(n=289, aspect=16 / 9), 3840, 2160, 32, 8),                   # C5's scene at 32 spp
+    "c5full": (lambda: stress_scene(n=289, aspect=16 / 9), 3840, 2160, 128, 8),              # configs[4] as stated
+    "ref": (lambda: reference_scene(aspect=800 / 600), 800, 600, 1, 5),                      # RayZen's own workload (main.cpp:35-36, 356-384, 600)
+}
+
+
+def named_config(name):
+    """(scene, width, height, spp, bounces) of one of NAMED_CONFIGS."""
+    make, w, h, spp, b = NAMED_CONFIGS[name]
+    return make(), w, h, spp, b

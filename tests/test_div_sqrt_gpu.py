@@ -28,6 +28,12 @@ def test_short_quotient_and_square_root_are_the_ieee_results_for_every_admitted_
     assert lines["PRODUCT sqrt_mid"].endswith("mismatches 0"), out.stdout
     assert "admitted 1677721601 inputs" in lines["PRODUCT sqrt_mid"], out.stdout         # 200 exponents x 2^23 mantissas + 2^100 itself
     assert lines["PRODUCT div_mid"].endswith("mismatches 0"), out.stdout
+    # the admission test that div3 / normalize actually call admits exactly what the scalar one admits (it used to
+    # let positive magnitudes below 2^-60 through), and everything it admits divides correctly
+    assert "PRODUCT div_mid_num3_ok vs div_mid_num_ok" in lines and "PRODUCT div3 admission" in lines, out.stdout
+    assert lines["PRODUCT div_mid_num3_ok vs div_mid_num_ok"].endswith("disagreements 0"), out.stdout
+    assert "4294967296 bit patterns" in lines["PRODUCT div_mid_num3_ok vs div_mid_num_ok"], out.stdout
+    assert lines["PRODUCT div3 admission"].endswith("mismatches 0"), out.stdout
     # the candidate sweeps that the product's form rests on: the one-correction quotient never missed
     for l in out.stdout.splitlines():
         if l.startswith("div: one correction"):

@@ -33,7 +33,7 @@ def test_oracle_reproduces_golden(key):
     want, wcnt = _load(key)
     got, cnt = oracle_render(mg.make_scene(c["scene"]), c["W"], c["H"], c["spp"], c["bounces"], want_counters=True)
     assert (got.view(np.uint32) == want.view(np.uint32)).all(), mismatch_report(got, want)
-    assert cnt == wcnt
+    assert {k: cnt[k] for k in wcnt} == wcnt       # (the fixtures hold the ten traversal-side tallies of rounds 1-3; the four shading-side ones of round 4 are compared HIP vs oracle in the parity tests)
 
 
 @pytest.mark.gpu
@@ -45,4 +45,4 @@ def test_hip_reproduces_golden(key):
     got, cnt = hip_render(mg.make_scene(c["scene"]), c["W"], c["H"], c["spp"], c["bounces"], counted=True)
     assert linf(got, want) < 1e-4, mismatch_report(got, want)
     assert (got.view(np.uint32) == want.view(np.uint32)).all(), mismatch_report(got, want)
-    assert cnt == wcnt
+    assert {k: cnt[k] for k in wcnt} == wcnt       # (the fixtures hold the ten traversal-side tallies of rounds 1-3; the four shading-side ones of round 4 are compared HIP vs oracle in the parity tests)
