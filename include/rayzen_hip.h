@@ -369,7 +369,7 @@ typedef struct rz_launch_plan {
     int32_t lds_stack_entries;  /* BLAS stack entries per lane kept in LDS */
     int32_t overflow_entries;   /* ... and in the global overflow columns (0: the whole stack fits the LDS window) */
     int32_t transparent;        /* 1: the scene has a transparent material (the speculating variant of the kernel) */
-    int32_t reserved;
+    int32_t scratch_mib;        /* MiB of scratch the launch's resident waves own (pools of parked paths + wait slots); 0: none */
 } rz_launch_plan;
 int rz_debug_last_plan(rz_ctx* ctx, rz_launch_plan* out);
 

@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r4k; mkdir -p $O
+for v in base e2 ${EXTRA}; do
+  RAYZEN_HIP_SO=$PWD/rayzen_amd/lib/librayzen_hip_$v.so timeout -k 10 200 python3 profiles/scripts/config_ms.py c2 >> $O/config_ms.log 2>&1
+done
+cat $O/config_ms.log

@@ -70,7 +70,7 @@ class LaunchPlan(C.Structure):
     """rz_launch_plan of include/rayzen_hip.h."""
     _fields_ = [("groups", C.c_int64), ("grid", C.c_int64), ("per_claim", C.c_int32), ("claim_units", C.c_int32),
                 ("batches_per_pixel", C.c_int32), ("pixels_per_wave", C.c_int32), ("lds_stack_entries", C.c_int32),
-                ("overflow_entries", C.c_int32), ("transparent", C.c_int32), ("reserved", C.c_int32)]
+                ("overflow_entries", C.c_int32), ("transparent", C.c_int32), ("scratch_mib", C.c_int32)]
 
 
 class Counters(C.Structure):

@@ -115,7 +115,9 @@ struct rz_ctx {
     int failAllocCountdown = 0;         // rz_debug_fail_alloc (test hook)
     // device re-layout (rz_relayout.hip): the caller's raw arrays on the device, the fill of dPairs / dTris, scratch
     DevBuf dRawNodes, dRawIdx, dRawTris, dRelayoutWs, dClaimScratch;
-    DevBuf dWavePools, dDeferAdd, dDeferFlags;     // the waves' cross-claim pools of parked paths, the waiting claims' addends and flags (rz_kernels.hip: pool_process)
+    DevBuf dSnap;                                  // transparent scenes: the resident waves' sample prefixes (rz_path.h: snapshot_store)
+    DevBuf dWavePools, dDeferAdd, dDeferFlags;     // the resident waves' pools of parked paths and the bookkeeping of their wait slots (rz_kernels.hip: pool_process; the slots themselves: dClaimScratch; dDeferAdd: unused since round 4)
+    size_t lastScratchBytes = 0;                   // what the last compacting launch's waves had in scratch (pools + wait slots + bookkeeping)
     int* relayoutPinned = nullptr;
     bool layoutOnDevice = false;        // dPairs / dTris were produced on the device (hPairs / hTris are empty)
     long long devPairsUsed = 0, devTrisUsed = 0;
@@ -667,48 +669,71 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
         if (rc != RZ_OK) return rc;
         K.blasOvf = static_cast<uint2*>(c->dBlasOvf.p);
     }
-    K.claimScratch = nullptr;
-    if (plan.compact && K.maxBounces < 65536) {          // per resident wave: the claim's addends + the pool of parked paths (rz_scene_dev.h)
-        size_t stride = claim_scratch_dwords(plan.claimUnits) + RZ_CLAIM_STRIDE_PAD;
-        if (const char* e = std::getenv("RZ_CLAIM_STRIDE_PAD")) stride = claim_scratch_dwords(plan.claimUnits) + (size_t)std::max(0, std::atoi(e));   // tuning aid (dwords)
-        rc = ensure(c, c->dClaimScratch, (size_t)plan.grid * stride * sizeof(float));
-        if (rc != RZ_OK) return rc;
-        K.claimScratch = static_cast<float*>(c->dClaimScratch.p);
-        K.claimStride = (uint32_t)stride;
-    }
-    K.wpool = nullptr; K.wpoolStride = 0; K.wpoolChunk = 0; K.daddends = nullptr; K.dflags = nullptr; K.dClaimStride = 0;
-    if (plan.crossClaimPool && K.claimScratch != nullptr && K.maxBounces > 2) {
-        // every resident wave keeps its pool of parked paths across claims: room for the chunk it collects before it traces
-        // them + the most one more claim can park; the addends of every claim (only the waiting ones are written) and a
-        // link per claim (each wave's list of its waiting claims; written before it is read, so never cleared)
+    // Compacting launches: every resident wave's scratch (rz_kernels.hip: WAIT SLOTS, pool_process) --
+    //   * its pool of parked paths: room for the chunk it collects before it traces them + the most one more claim can park;
+    //   * its claim scratch (the addends of the claim it is running, 1.5 KB per unit) and behind it its wait slots, one waiting
+    //     group's addends (batches x 1.5 KB) each: at least twice the groups of a claim, 32 / batches by default (a claim that
+    //     finds fewer free ones than it has groups makes the wave trace its pool first; RZ_WAIT_SLOTS overrides);
+    //   * 4 ints of bookkeeping per slot.
+    // C2: 83 + 12 + 48 KB per wave, 0.59 GB for the grid (round 3: 3.7 GB, of which 3.2 GB an array of 1.5 KB per unit of the launch).
+    // The scratch is optional: a launch that cannot have it (or is told so: RZ_DEBUG_NO_POOL_MEMORY=1, a test aid) runs the
+    // plain persistent loop instead, same image.
+    K.wslots = nullptr; K.wslotStride = 0; K.slotFloats = 0; K.nWaitSlots = 0; K.wmeta = nullptr; K.drainEachClaim = 0; K.claimUnits = 0;
+    K.wpool = nullptr; K.wpoolStride = 0; K.wpoolChunk = 0;
+    if (plan.compact && K.maxBounces < 65536) {
         long long chunk = RZ_WPOOL_CHUNK;
         if (const char* e = std::getenv("RZ_WPOOL_CHUNK")) chunk = std::max<long long>(1, std::atoll(e));      // tuning / test aid
-        // (the addends array is 1.5 KB per unit of the launch -- 3.2 GB for a 1080p frame at 64 spp, 25 GB for 4K at 128 spp -- of
-        //  which only the waiting claims' parts are touched: sized for a 288-GB part, and done without where it does not fit)
+        const int nBatches = (K.spp + 63) / 64;
+        const int groupsPerClaim = std::max(1, plan.perClaim);
+        int nSlots = std::max(2 * groupsPerClaim, 32 / nBatches);
+        if (const char* e = std::getenv("RZ_WAIT_SLOTS")) nSlots = std::max(2 * groupsPerClaim, std::atoi(e));  // tuning / test aid
+        nSlots = std::min(nSlots, 64);
         const size_t stride = (size_t)chunk + (size_t)plan.claimUnits * 64 + 64;
-        const size_t claimFloats = (size_t)plan.claimUnits * 384;
+        const size_t slotFloats = (size_t)nBatches * 384;
+        size_t slotPad = 0;                                                                                      // floats between neighbouring waves' slot regions
+        if (const char* e = std::getenv("RZ_SLOT_STRIDE_PAD")) slotPad = (size_t)std::max(0, std::atoi(e));     // tuning aid
         const char* forceNo = std::getenv("RZ_DEBUG_NO_POOL_MEMORY");      // test aid: as if the device had no room for it
-        if (!(forceNo && std::atoi(forceNo) != 0) &&
+        if (nSlots >= groupsPerClaim && !(forceNo && std::atoi(forceNo) != 0) &&
             ensure_optional(c->dWavePools, (size_t)plan.grid * stride * RZ_GPOOL_FIELDS * sizeof(unsigned)) &&
-            ensure_optional(c->dDeferAdd, (size_t)plan.nClaims * claimFloats * sizeof(float)) &&
-            ensure_optional(c->dDeferFlags, (size_t)plan.nClaims * sizeof(int32_t))) {
+            ensure_optional(c->dClaimScratch, (size_t)plan.grid * ((size_t)plan.claimUnits * 384 + nSlots * slotFloats + slotPad) * sizeof(float)) &&
+            ensure_optional(c->dDeferFlags, (size_t)plan.grid * 4 * nSlots * sizeof(int32_t))) {
             K.wpool = static_cast<unsigned*>(c->dWavePools.p);
             K.wpoolStride = (uint32_t)stride;
             K.wpoolChunk = (uint32_t)chunk;
-            K.daddends = static_cast<float*>(c->dDeferAdd.p);
-            K.dflags = static_cast<int32_t*>(c->dDeferFlags.p);
-            K.dClaimStride = (uint32_t)claimFloats;
+            K.wslots = static_cast<float*>(c->dClaimScratch.p);
+            K.wslotStride = (uint32_t)((size_t)plan.claimUnits * 384 + nSlots * slotFloats + slotPad);
+            K.claimUnits = plan.claimUnits;
+            K.slotFloats = (uint32_t)slotFloats;
+            K.nWaitSlots = nSlots;
+            K.wmeta = static_cast<int32_t*>(c->dDeferFlags.p);
+            K.drainEachClaim = plan.drainEachClaim ? 1 : 0;
         }
     }
-    c->lastGlobalPool = K.wpool != nullptr;
+    c->lastGlobalPool = K.wpool != nullptr && K.drainEachClaim == 0;
+    c->lastScratchBytes = K.wpool ? (size_t)plan.grid * ((size_t)K.wpoolStride * RZ_GPOOL_FIELDS * 4 + (size_t)K.wslotStride * 4 + (size_t)16 * K.nWaitSlots) : 0;
+    // transparent scenes, persistent launches: room for every resident wave's sample prefixes (19 + 14 dwords per lane, 34 MB for
+    // the grid), so that a sample's second version starts at its first transparent scatter instead of at the camera.
+    // RZ_GLASS_SNAPSHOT=0 switches it off (A/B aid: same image either way).
+    K.snap = nullptr; K.snapStride = 0;
+    if (c->sceneHasTransparency && plan.perClaim > 0) {
+        bool on = true;
+        if (const char* e = std::getenv("RZ_GLASS_SNAPSHOT")) on = std::atoi(e) != 0;
+        const size_t stride = (size_t)(RZ_SNAP_FIELDS + RZ_SNAP_TALLY) * 64;
+        if (on) {
+            rc = ensure(c, c->dSnap, (size_t)plan.grid * stride * sizeof(float));
+            if (rc != RZ_OK) return rc;
+            K.snap = static_cast<float*>(c->dSnap.p);
+            K.snapStride = (uint32_t)stride;
+        }
+    }
     RZ_HIP(c, hipEventRecord(c->evStart[evSlot], c->stream));
     if (K.nSlots > 0) launch_render_samples(K, counted, c->sceneHasTransparency, c->stream);
     RZ_HIP(c, hipEventRecord(c->evStop[evSlot], c->stream));
     c->lastLaunches = K.nSlots > 0 ? 1 : 0;
     c->lastGrid = plan.grid;
-    c->lastPlan = rz_launch_plan{plan.groups, plan.grid, plan.perClaim, (plan.compact && K.claimScratch) ? plan.claimUnits : 0,
+    c->lastPlan = rz_launch_plan{plan.groups, plan.grid, plan.perClaim, (plan.compact && K.wpool) ? plan.claimUnits : 0,
                                  (K.spp + 63) / 64, K.spp >= 64 ? 1 : 64 / K.spp, K.blasStackCap, K.blasOvfCap,
-                                 c->sceneHasTransparency ? 1 : 0, 0};
+                                 c->sceneHasTransparency ? 1 : 0, (int32_t)((c->lastScratchBytes + (1u << 20) - 1) >> 20)};
     return RZ_OK;
 }
 
@@ -822,6 +847,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
         fprintf(stderr, "[rz_prof] compacting claims: phase 1 (units) %llu  pool rounds %llu wave cycles; %llu rounds with %llu paths = %.1f lanes per round\n", pr[23], pr[28], pr[29], pr[30], pr[29] ? (double)pr[30] / (double)pr[29] : 0.0);
         fprintf(stderr, "[rz_prof] cross-claim pools: %llu traced, %llu queries in them, shade rounds %llu wave cycles\n", pr[29], pr[30], pr[28]);
         fprintf(stderr, "[rz_prof] pool_trace (a claim's pooled queries traced together): %llu wave cycles = T phases %llu + B phases %llu (of which refills %llu); round 7 above = its steps\n", pr[120], pr[121], pr[122], pr[123]);
+        fprintf(stderr, "[rz_prof] wait slots: end-of-claim sections %llu wave cycles (of which the claim-end sums %llu); slot_sums inside pool_process %llu\n", pr[124], pr[126], pr[125]);
         fprintf(stderr, "[rz_prof] inside advance: sky %llu  hit %llu  start_light %llu  shade_light %llu  scatter %llu (hemisphere %llu)  shadow step %llu\n", pr[22], pr[23], pr[24], pr[25], pr[26], pr[27], pr[28]);
 #endif
     }
@@ -894,7 +920,7 @@ void rz_destroy(rz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
-                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs, &c->dTlasDfs, &c->dTriN, &c->dRawNodes, &c->dRawIdx, &c->dRawTris, &c->dRelayoutWs, &c->dClaimScratch, &c->dWavePools, &c->dDeferAdd, &c->dDeferFlags})
+                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs, &c->dTlasDfs, &c->dTriN, &c->dRawNodes, &c->dRawIdx, &c->dRawTris, &c->dRelayoutWs, &c->dClaimScratch, &c->dWavePools, &c->dDeferAdd, &c->dDeferFlags, &c->dSnap})
         b->release();
     if (c->tlasHostCounts) (void)hipHostFree(c->tlasHostCounts);
     if (c->relayoutPinned) (void)hipHostFree(c->relayoutPinned);

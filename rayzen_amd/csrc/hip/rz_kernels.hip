@@ -191,7 +191,7 @@ __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
     a.triangles_past_u += b.triangles_past_u; a.scatters += b.scatters; a.diffuse_scatters += b.diffuse_scatters; a.hemi_draws += b.hemi_draws; a.lit_lights += b.lit_lights;
 #ifdef RZ_PROF
     for (int k = 0; k < 16; ++k) a.p[k] += b.p[k];
-    for (int k = 0; k < 16; ++k) a.t[k] += b.t[k];
+    for (int k = 0; k < 20; ++k) a.t[k] += b.t[k];
     for (int r = 0; r < 8; ++r) { a.rt[r] += b.rt[r]; for (int k = 0; k < 10; ++k) a.rp[r][k] += b.rp[r][k]; }
 #endif
 }
@@ -227,9 +227,6 @@ __device__ __forceinline__ void tally_flush(const KParams& K, const Tally& c) {
 #define RZ_SPREAD_ON(K) (SPREAD && (K).spreadTrace != 0)
 #ifndef RZ_CLAIM_RUN_SMALL_SPP
 #define RZ_CLAIM_RUN_SMALL_SPP 1
-#endif
-#ifndef RZ_CROSS_POOL_MIN_UNITS
-#define RZ_CROSS_POOL_MIN_UNITS (256ll << 10)
 #endif
 #ifndef RZ_PARK_BOUNCE
 #define RZ_PARK_BOUNCE 2         // a path is parked when it stands in front of this segment (0-based: its third)
@@ -410,7 +407,15 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
                     P.color = mk3(0.0f, 0.0f, 0.0f);
                     P.ior = want;
                     P.samp = K.sampleBase + s;
-                    begin_sample<COUNT>(K, P, COUNT ? att : c);
+                    if (firstPass || K.snap == nullptr) {
+                        begin_sample<COUNT>(K, P, COUNT ? att : c);
+                    } else {
+                        // a second version: only a sample that READ currentIor is ever run again, and its first run has left the
+                        // state in front of that read -- its first transparent scatter -- in the wave's scratch (rz_path.h:
+                        // snapshot_store): camera ray, queries and first-hit lighting up to there do not depend on currentIor
+                        snapshot_load<COUNT>(K, P, COUNT ? att : c);
+                        scatter<COUNT, true, false>(K, P, COUNT ? att : c);
+                    }
                 }
                 // (a per-lane loop here: as a wave-uniform loop with a predicated body, which pays in the opaque variant, this
                 //  one lost 3 % -- 26.1 -> 27.0 ms on the glass + mirror scene)
@@ -426,12 +431,12 @@ __device__ __forceinline__ void render_samples_group(const KParams& K, const uns
                                            ? trace_spread<false, OVF>(K, P.o, P.d, h, bstk, c) : trace_closest<false, OVF>(K, P.o, P.d, h, bstk, c);
                     c.rt[c.rnd & 7] += __builtin_amdgcn_s_memtime() - tq0_;
                     if (c.rnd < 7) ++c.rnd;
-                    advance<false, true>(K, P, found, h, c);
+                    advance<false, true, true>(K, P, found, h, c);
 #else
                     // (the lanes still in this loop have spread once they all are on their third or a later segment: rz_trace.h, trace_spread)
                     const bool found = (RZ_SPREAD_ON(K) && rz_ballot(!(P.mode == MODE_SEGMENT && P.bounce >= 2)) == 0ull)
                                            ? trace_spread<COUNT, OVF>(K, P.o, P.d, h, bstk, COUNT ? att : c) : trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, COUNT ? att : c);
-                    advance<COUNT, true>(K, P, found, h, COUNT ? att : c);
+                    advance<COUNT, true, true>(K, P, found, h, COUNT ? att : c);
 #endif
                 }
                 if (run) {
@@ -543,126 +548,159 @@ struct ClaimMap {
     }
 };
 
-// The ordered sums of a claim's pixels from its addends ([unit][6][64] floats at addBase): 21 pixels per pass, lane 3 q + ch
-// replays the additions of channel ch of the pass's q-th pixel in sample order, FS:717 then FS:709, sample after sample
-// (spp >= 64: a claim has at most 16 pixels -- one pass, 24 or 48 lanes busy; spp < 64: up to 64 pixels per unit, each summing
-// its spp entries of one unit's addends).  Run at the end of a claim, or -- for a claim that waited for parked paths -- by its wave at the end of the launch, when
-// the wave's pool has run dry.
+// ---------------------------------------------------------------------------------------------------------
+// WAIT SLOTS (round 4): when a group's pixels are summed, and where its addends wait.
+//
+// Round 3 deferred per CLAIM: a claim with ONE parked path copied all its units' addends to a per-launch array of 1.5 KB per
+// unit (3.2 GB at 1080p / 64 spp, 25 GB for C5) and all its pixels waited for the end of the wave's life.  Now a resident wave
+// owns its claim scratch (the addends of the claim it is running, [unit][6][64] floats, as before: the units' stores and the
+// sums stay in the cache) and K.nWaitSlots WAIT SLOTS of nBatches x 384 floats -- one GROUP's addends each -- and:
+//   * at the end of a claim the wave counts the claim's parked paths per group (ballots over the pool entries it has just
+//     written); a group without one is summed at once from the claim scratch (two thirds of C2's pixels);
+//   * a group with parked paths gets a slot off the wave's free stack: its addends are copied there (1.5 KB per batch; round 3
+//     copied the whole claim), its pool entries are told the slot, `outstanding[slot]` = its paths in the pool;
+//   * a path that ends writes its sky term into the slot and decrements the count; the group is summed -- and its slot freed --
+//     in the pool pass in which its last path comes back, not at the end of the launch;
+//   * a claim may start only when as many slots are free as it has groups: otherwise the wave traces its pool first (every pass
+//     ends paths; an empty pool means that every slot is free).
+// Scratch per resident wave on C2: pool 83 KB + claim scratch 12 KB + 32 slots x 1.5 KB = 143 KB, 0.59 GB for the grid, where
+// round 3 took 3.7 GB; C5: 0.9 GB where it took 25.
+// The meta block of a wave (ints): [0, NS) the launch-order index of the group in the slot | [NS, 2 NS) outstanding paths |
+// [2 NS, 3 NS) the free stack | [3 NS, 4 NS) the slots that became ready in the current pass.  It is read with vector loads at
+// workgroup scope (the scalar cache is not coherent with the wave's own stores), the one-wave workgroup's __syncthreads()
+// order the stores of a phase before the loads of the next.  Nothing per UNIT touches it: a dependent load per unit -- the first
+// version read the group's slot there -- cost the frame 10 % (one exposed memory round trip, 500 times per wave).
+__device__ __forceinline__ int wmeta_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// One pass of ordered sums: lane 3 q + ch replays the additions of channel ch of the pass's q-th pixel (q < 21) in sample
+// order, FS:717 then FS:709, sample after sample, from the group's addends A ([batch][6][64] floats); `slot` is the pixel's index
+// in launch order (its tile and place in the tile), `lane0` its first lane in a batch (spp < 64: pixel-in-group x spp).
 template <bool COUNT>
-__device__ __forceinline__ void claim_ordered_sums(const KParams& K, const ClaimMap& M, const unsigned ci, const float* __restrict__ addBase,
-                                                   const int nPix, const int ppw, const int nBatches) {
+__device__ __forceinline__ void ordered_sum_pass(const KParams& K, const bool valid, const float* __restrict__ A, const int slot, const int lane0) {
     const int lane = threadIdx.x & 63;
     const int spp = K.spp;
-    for (int p0 = 0; p0 < nPix; p0 += 21) {
-        const int q = lane / 3, ch = lane - 3 * q;
-        const int p = p0 + q;
-        bool inside = false;
-        size_t pix = 0;
-        float chan = 0.0f, alpha = 0.0f;
-        if (q < 21 && p < nPix) {
-            const int gq = p / ppw;
-            const int slot = M.group(ci, gq) * ppw + (p - gq * ppw);
-            const int localTile = slot >> 6, l = slot & 63;
-            const int tile = localTile * K.tileNRanks + K.tileRank;
-            const int ty = tile / K.tilesX, tx = tile - ty * K.tilesX;
-            const int px = tx * RZ_TILE_W + slot_x(l, spp < 64), py = ty * RZ_TILE_H + slot_y(l, spp < 64);
-            if (slot < K.nSlots && px < K.width && py < K.height) {
-                inside = true;
-                pix = (size_t)py * K.width + px;
-                if (K.sampleBase != 0) {
-                    const float4 a = K.accum[pix];
-                    chan = ch == 0 ? a.x : (ch == 1 ? a.y : a.z);
-                    alpha = a.w;
-                }
+    const int nBatches = (spp + 63) / 64;
+    const int q = lane / 3, ch = lane - 3 * q;
+    bool inside = false;
+    size_t pix = 0;
+    float chan = 0.0f, alpha = 0.0f;
+    if (valid) {
+        const int localTile = slot >> 6, l = slot & 63;
+        const int tile = localTile * K.tileNRanks + K.tileRank;
+        const int ty = tile / K.tilesX, tx = tile - ty * K.tilesX;
+        const int px = tx * RZ_TILE_W + slot_x(l, spp < 64), py = ty * RZ_TILE_H + slot_y(l, spp < 64);
+        if (slot < K.nSlots && px < K.width && py < K.height) {
+            inside = true;
+            pix = (size_t)py * K.width + px;
+            if (K.sampleBase != 0) {
+                const float4 a = K.accum[pix];
+                chan = ch == 0 ? a.x : (ch == 1 ? a.y : a.z);
+                alpha = a.w;
             }
         }
-        if (inside) {
-            const int g = p / ppw, lane0 = (p - g * ppw) * spp;      // spp < 64: the pixel's unit and its first lane there
-            for (int b = 0; b < nBatches; ++b) {
-                const float* Lf = addBase + (size_t)(spp >= 64 ? p * nBatches + b : g) * 384 + 64 * ch + (spp >= 64 ? 0 : lane0);
-                const float* Sf = Lf + 192;
-                const int n = spp >= 64 ? min(64, spp - b * 64) : spp;
-                int k = 0;
-                for (; k + 8 <= n; k += 8) {
-                    float l[8], q8[8];
+    }
+    if (inside) {
+        for (int b = 0; b < nBatches; ++b) {
+            const float* Lf = A + (size_t)b * 384 + 64 * ch + lane0;
+            const float* Sf = Lf + 192;
+            const int cnt = spp >= 64 ? min(64, spp - b * 64) : spp;
+            int k = 0;
+            for (; k + 8 <= cnt; k += 8) {
+                float l[8], q8[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { l[u] = Lf[k + u]; q8[u] = Sf[k + u]; }
+                for (int u = 0; u < 8; ++u) { l[u] = Lf[k + u]; q8[u] = Sf[k + u]; }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { chan = chan + l[u]; chan = chan + q8[u]; }   // FS:717, FS:709
-                }
-                for (; k < n; ++k) { chan = chan + Lf[k]; chan = chan + Sf[k]; }
+                for (int u = 0; u < 8; ++u) { chan = chan + l[u]; chan = chan + q8[u]; }   // FS:717, FS:709
             }
+            for (; k < cnt; ++k) { chan = chan + Lf[k]; chan = chan + Sf[k]; }
         }
-        const int l0 = q < 21 ? 3 * q : 0;
-        const float cx = __shfl(chan, l0), cy = __shfl(chan, l0 + 1), cz = __shfl(chan, l0 + 2);
-        if (inside && ch == 0) {
-            K.accum[pix] = make_float4(cx, cy, cz, alpha + (float)spp);
-            K.ior[pix] = 1.0f;
-        }
-        if (COUNT) {
-            const unsigned long long im = rz_ballot(inside && ch == 0);
-            if (lane == 0 && im) atomicAdd(&K.counters->pixels, (unsigned long long)__popcll(im));
-        }
+    }
+    const int l0 = q < 21 ? 3 * q : 0;
+    const float cx = __shfl(chan, l0), cy = __shfl(chan, l0 + 1), cz = __shfl(chan, l0 + 2);
+    if (inside && ch == 0) {
+        K.accum[pix] = make_float4(cx, cy, cz, alpha + (float)spp);
+        K.ior[pix] = 1.0f;
+    }
+    if (COUNT) {
+        const unsigned long long im = rz_ballot(inside && ch == 0);
+        if (lane == 0 && im) atomicAdd(&K.counters->pixels, (unsigned long long)__popcll(im));
     }
 }
 
+// The ordered sums of the pixels of the `n` groups whose slots stand in the wave's ready list, 21 pixels per pass; then the slots
+// go back on the free stack.
+template <bool COUNT>
+__device__ __forceinline__ void slot_sums(const KParams& K, const float* __restrict__ slotsBase, int* __restrict__ meta, const int n, int& freeCount) {
+    const int lane = threadIdx.x & 63;
+    const int spp = K.spp, NS = K.nWaitSlots;
+    const int ppw = spp >= 64 ? 1 : 64 / spp;
+    const int nPix = n * ppw;
+    for (int p0 = 0; p0 < nPix; p0 += 21) {
+        const int q = lane / 3;
+        const int p = p0 + q;
+        const bool valid = q < 21 && p < nPix;
+        const float* A = slotsBase;
+        int slot = 0, pin = 0;
+        if (valid) {
+            const int r = p / ppw;
+            pin = p - r * ppw;
+            const int sl = wmeta_load(meta + 3 * NS + r);
+            slot = wmeta_load(meta + sl) * ppw + pin;
+            A = slotsBase + (size_t)sl * K.slotFloats;
+        }
+        ordered_sum_pass<COUNT>(K, valid, A, slot, pin * (spp >= 64 ? 0 : spp));
+    }
+    // the summed groups' slots are free again (n <= NS <= 64: one lane each)
+    if (lane < n) meta[2 * NS + freeCount + lane] = wmeta_load(meta + 3 * NS + lane);
+    freeCount += n;
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------------------
-// render_claim_compact: the opaque spp >= 64 persistent path with RAY COMPACTION across the pixels of a claim
+// render_claim_compact: the opaque persistent path with RAY COMPACTION across the pixels of a claim
 // (north_star: "wavefront ballot / prefix-sum ray compaction for divergent bounces").
-// A claim is up to UNITS (pixel, 64-sample batch) units.  The wave runs the units one after the other as
-// before, but a path that is about to trace its THIRD segment (bounce >= 2: 5 % of C2's paths, scattered over lanes
-// whose neighbours have died) is parked instead: its 13 dwords of state + a back reference go to a pool in the wave's
-// scratch, at slot nPool + (number of parked lanes below it) -- a ballot and a popcount of the lower lanes.  When the
-// claim's units are through, the pool is worked off 64 paths at a time: full waves instead of 8 x 44 / 8 x 21 live
-// lanes (C2), with the same trace / advance code (ONE inlined copy serves both phases).  The two addends of every
-// sample go to the wave's scratch instead of LDS (the pixel's ordered sum needs the parked samples' sky term), and
-// the ordered sums of the whole claim run at its end, one lane per (pixel, colour channel): 24 lanes at once instead
-// of 3 lanes eight times.  A path's arithmetic does not depend on where it runs: same bits.
-// Scratch is private to the resident wave and is only ever read by the wave that wrote it (L1/L2 hits); the
-// __syncthreads() of the one-wave workgroup order its stores before its loads.
+// A claim is up to UNITS (pixel, 64-sample batch) units (spp < 64: groups of 64 / spp pixels).  The wave runs the units one
+// after the other, but a path that is about to trace its THIRD segment (bounce >= 2: 5 % of C2's paths, scattered over lanes
+// whose neighbours have died) is parked instead: its 13 dwords of state + a back reference (unit, lane) go to the wave's
+// pool, at position (paths already there) + (number of parked lanes below it) -- a ballot and a popcount of the lower lanes.  The
+// pool is kept ACROSS the wave's claims and traced when it has filled up (pool_process).  The two addends of every sample go to
+// the wave's claim scratch; at the end of the claim the groups without a parked path are summed, one lane per (pixel, colour
+// channel): 24 lanes at once instead of 3 lanes eight times, and the others move to wait slots (above).  A path's arithmetic
+// does not depend on where it runs: same bits.
+// All scratch is private to the resident wave (L1 / L2 hits); the __syncthreads() of the one-wave workgroup order its stores
+// before its loads.
 template <bool COUNT, bool OVF, int UNITS>
-__device__ __forceinline__ void render_claim_compact(const KParams& K, const ClaimMap M, const unsigned ci, unsigned char* lds_raw, int& wpN, int& wpHead) {
+__device__ __forceinline__ void render_claim_compact(const KParams& K, const ClaimMap M, const unsigned ci, unsigned char* lds_raw, int& wpN, int& freeCount) {
+    using namespace poolf;
     const int lane = threadIdx.x & 63;
     const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + lane,
                                OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + lane : nullptr, K.blasStackCap};
-    float* const addBase = K.claimScratch + (size_t)blockIdx.x * K.claimStride;
-    unsigned* const pool = reinterpret_cast<unsigned*>(addBase + (size_t)UNITS * 6 * 64);
-    constexpr int PS = UNITS * 64;                    // pool stride (slots per field)
-    // the wave's pool ACROSS claims (large launches): paths are parked there, behind the wpN it already holds, and the claim
-    // does not work them off itself (pool_process, when the pool has filled up)
-    const bool crossClaim = K.wpool != nullptr;
-    unsigned* const W = crossClaim ? K.wpool + (size_t)blockIdx.x * K.wpoolStride * RZ_GPOOL_FIELDS : nullptr;
+    float* const addBase = K.wslots + (size_t)blockIdx.x * K.wslotStride;         // the claim scratch: [unit][6][64]
+    unsigned* const W = K.wpool + (size_t)blockIdx.x * K.wpoolStride * RZ_GPOOL_FIELDS;
     const size_t WS = K.wpoolStride;
     const int spp = K.spp;
     const int nBatches = (spp + 63) / 64;
     // a unit is one wave's worth of samples: a 64-sample batch of one pixel (spp >= 64), or all spp samples of each of the
     // ppw = 64 / spp pixels of a group (spp < 64: lane = pixel-in-group * spp + sample, the pixels a compact block of the tile)
     const int ppw = spp >= 64 ? 1 : 64 / spp;
-    const int nGroups = M.units_of(ci);
-    const int nPix = nGroups * ppw;                   // pixels of the claim: slots base * ppw ... + nPix - 1
-    const int nUnits = nGroups * nBatches;            // <= UNITS by the launch plan
+    const int nGroups = M.units_of(ci);               // <= UNITS / nBatches <= 16 by the launch plan; the caller has seen to it that as many wait slots are free
+    const int nUnits = nGroups * nBatches;
     const int pixInUnit = spp >= 64 ? 0 : lane / spp; // (a lane with pixInUnit >= ppw is idle: spp need not divide 64)
     const int sampInUnit = spp >= 64 ? lane : lane - pixInUnit * spp;
-    int nPool = 0, unit = 0, poolBase = 0, poolWrite = 0;     // wave-uniform
+    int nPool = 0;                                            // wave-uniform: paths this claim has parked so far
     int tileCached = -1, tileX = 0, tileY = 0;                // wave-uniform: the tile of the current unit
     Tally c = {};
-    unsigned guard = 0;
-    bool cont;
-    bool claimDeferred = false;     // wave-uniform: the claim's parked paths went to the wave's cross-claim pool (its pixels are summed later)
-    do {                                                        // (one exit, at the end: see blas_walk; the bound is a backstop: units + pool rounds of at most maxBounces generations)
-        const bool phase2 = unit >= nUnits;
-        Path P;         // (per round: nothing of a path lives across rounds -- declared outside, all its fields stayed allocated across pool_trace)
+    for (int unit = 0; unit < nUnits; ++unit) {
+        Path P;         // (per unit: nothing of a path lives across units)
 #ifdef RZ_PROF
         const unsigned long long tph0_ = __builtin_amdgcn_s_memtime();
 #endif
-        int backUnit = 0, backLane = lane;
-        bool poolLane = false;
         P.mode = MODE_DONE;
         P.addLight = mk3(0.0f, 0.0f, 0.0f);
         P.addSky = mk3(0.0f, 0.0f, 0.0f);
         P.usedIor = 0;
         P.ior = 1.0f;
-        if (!phase2) {
+        {
             const int g = nBatches == 1 ? unit : unit / nBatches, b = unit - g * nBatches;
             const int slot = M.group(ci, g) * ppw + pixInUnit;
             const int localTile = slot >> 6, l = slot & 63;
@@ -692,33 +730,13 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
                 P.samp = K.sampleBase + s;
                 begin_sample<COUNT>(K, P, c);
             }
-        } else {
-            const int sl = poolBase + lane;
-            poolLane = sl < nPool;
-            if (poolLane) {
-                P.o = mk3(__uint_as_float(pool[0 * PS + sl]), __uint_as_float(pool[1 * PS + sl]), __uint_as_float(pool[2 * PS + sl]));
-                P.d = mk3(__uint_as_float(pool[3 * PS + sl]), __uint_as_float(pool[4 * PS + sl]), __uint_as_float(pool[5 * PS + sl]));
-                P.throughput = mk3(__uint_as_float(pool[6 * PS + sl]), __uint_as_float(pool[7 * PS + sl]), __uint_as_float(pool[8 * PS + sl]));
-                P.seed.x = __uint_as_float(pool[9 * PS + sl]);
-                P.seed.y = __uint_as_float(pool[10 * PS + sl]);
-                P.samp = (int)pool[11 * PS + sl];
-                const unsigned bb = pool[12 * PS + sl];
-                P.bounce = (int)(bb >> 16);
-                backUnit = (int)((bb >> 6) & 1023u);
-                backLane = (int)(bb & 63u);
-                P.color = mk3(0.0f, 0.0f, 0.0f);
-                P.mode = MODE_SEGMENT;
-            }
         }
-        // ONE trace / advance loop serves both phases.  Phase 1: a unit's paths run until they finish or stand in front
-        // of their third segment (bounce >= 2).  Phase 2: every pooled path runs exactly one segment (there are no shadow
-        // queries after bounce 0), so the survivors can be compacted again before the next bounce.
-        const int stopBounce = phase2 ? P.bounce + 1 : RZ_PARK_BOUNCE;
+        // A unit's paths run until they finish or stand in front of their third segment (bounce >= 2).
         // (one exit, at the end of the body: see blas_walk)
-        bool run = P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= stopBounce);
+        bool run = P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= RZ_PARK_BOUNCE);
         bool anyRun = rz_ballot(run) != 0ull;
 #ifdef RZ_PROF
-        c.rnd = phase2 ? (P.bounce + 2 < 7 ? P.bounce + 2 : 7) : 0;
+        c.rnd = 0;
 #endif
         while (anyRun) {
             if (run) {
@@ -727,8 +745,6 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
                 RZ_SITE(c, 6);
                 const unsigned long long tq0_ = __builtin_amdgcn_s_memtime();
 #endif
-                // (a claim's own pool -- small launches -- is worked off 64 paths at a time by the wave-cursor walk, as in round 2:
-                //  the lane-refilling tracer needs a list much longer than a claim's few dozen paths, see pool_process)
                 const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, c);
 #ifdef RZ_PROF
                 c.rt[c.rnd & 7] += __builtin_amdgcn_s_memtime() - tq0_;
@@ -738,108 +754,129 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
 #ifdef RZ_PROF
             if (c.rnd < 7) ++c.rnd;
 #endif
-            run = P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= stopBounce);
+            run = P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= RZ_PARK_BOUNCE);
             anyRun = rz_ballot(run) != 0ull;
         }
         const bool parked = P.mode != MODE_DONE;
         const unsigned long long pm = rz_ballot(parked);
-        if (!phase2) {
+        {
             float* const A = addBase + (size_t)unit * 384;
             A[lane] = P.addLight.x; A[64 + lane] = P.addLight.y; A[128 + lane] = P.addLight.z;        // FS:717
             A[192 + lane] = P.addSky.x; A[256 + lane] = P.addSky.y; A[320 + lane] = P.addSky.z;       // FS:709 (parked: still 0)
-            backUnit = unit;
-        } else if (poolLane && !parked) {
-            float* const A = addBase + (size_t)backUnit * 384;
-            A[192 + backLane] = P.addSky.x; A[256 + backLane] = P.addSky.y; A[320 + backLane] = P.addSky.z;
         }
-        // compaction: parked lane -> pool slot (write cursor) + (number of parked lanes below it).  In phase 2 the write
-        // cursor trails the read cursor (a round reads 64 slots and parks at most 64), so the pool is compacted in place.
-        const int wbase = phase2 ? poolWrite : (crossClaim ? wpN + nPool : nPool);
+        // compaction: parked lane -> pool position (paths already there) + (number of parked lanes below it)
         if (parked) {
-            const int sl = wbase + __popcll(pm & ((1ull << lane) - 1ull));
-            unsigned* const Q = crossClaim ? W : pool;
-            const size_t qs = crossClaim ? WS : (size_t)PS;
-            Q[0 * qs + sl] = __float_as_uint(P.o.x); Q[1 * qs + sl] = __float_as_uint(P.o.y); Q[2 * qs + sl] = __float_as_uint(P.o.z);
-            Q[3 * qs + sl] = __float_as_uint(P.d.x); Q[4 * qs + sl] = __float_as_uint(P.d.y); Q[5 * qs + sl] = __float_as_uint(P.d.z);
-            Q[6 * qs + sl] = __float_as_uint(P.throughput.x); Q[7 * qs + sl] = __float_as_uint(P.throughput.y);
-            Q[8 * qs + sl] = __float_as_uint(P.throughput.z);
-            Q[9 * qs + sl] = __float_as_uint(P.seed.x); Q[10 * qs + sl] = __float_as_uint(P.seed.y);
-            Q[11 * qs + sl] = (unsigned)P.samp;
-            Q[12 * qs + sl] = ((unsigned)P.bounce << 16) | ((unsigned)backUnit << 6) | (unsigned)backLane;
-            if (crossClaim) Q[(size_t)(RZ_GPOOL_FIELDS - 1) * qs + sl] = ci;
+            const size_t sl = (size_t)(wpN + nPool) + __popcll(pm & ((1ull << lane) - 1ull));
+            W[OX * WS + sl] = __float_as_uint(P.o.x); W[OY * WS + sl] = __float_as_uint(P.o.y); W[OZ * WS + sl] = __float_as_uint(P.o.z);
+            W[DX * WS + sl] = __float_as_uint(P.d.x); W[DY * WS + sl] = __float_as_uint(P.d.y); W[DZ * WS + sl] = __float_as_uint(P.d.z);
+            W[TPX * WS + sl] = __float_as_uint(P.throughput.x); W[TPY * WS + sl] = __float_as_uint(P.throughput.y);
+            W[TPZ * WS + sl] = __float_as_uint(P.throughput.z);
+            W[SEEDX * WS + sl] = __float_as_uint(P.seed.x); W[SEEDY * WS + sl] = __float_as_uint(P.seed.y);
+            W[SAMP * WS + sl] = (unsigned)P.samp;
+            W[BACK * WS + sl] = ((unsigned)P.bounce << 16) | ((unsigned)unit << 6) | (unsigned)lane;     // (the unit becomes the batch within its group at the end of the claim)
         }
-        bool deferred = false;
-        if (!phase2) {
-            nPool += __popcll(pm);
-            ++unit;
-            if (unit >= nUnits) {
-                __syncthreads();       // the pool is read next
-                if (crossClaim && nPool > 0) {
-                    // the claim's pixels wait for its parked paths: its addends move to the launch's buffer, the claim joins the
-                    // list of this wave's waiting claims (linked through K.dflags, newest first: the paths are in THIS wave's
-                    // pool, so the wave itself adds the pixels up once its pool has run dry) and the wave goes on
-                    float* const D = K.daddends + (size_t)ci * K.dClaimStride;
-                    for (int k = lane; k < nUnits * 384; k += 64) D[k] = addBase[k];
-                    if (lane == 0) K.dflags[ci] = wpHead;
-                    wpHead = (int)ci + 1;
-                    wpN += nPool;
-                    deferred = true;
-                    claimDeferred = true;
-                }
-            }
-        } else {
-            poolWrite += __popcll(pm);
-            poolBase += 64;
-        }
+        nPool += mask_count(pm);
 #ifdef RZ_PROF
-        {   // diagnostic build: wave cycles and lane occupancy of the two phases of a claim
-            const unsigned long long dt_ = __builtin_amdgcn_s_memtime() - tph0_;
-            if (phase2) { c.t[9] += dt_; c.t[10] += 1; c.t[11] += (unsigned long long)__popcll(rz_ballot(poolLane)); }   // pool rounds and the paths in them
-            else { c.t[4] += dt_; }
-        }
+        c.t[4] += __builtin_amdgcn_s_memtime() - tph0_;
 #endif
-        cont = !deferred;
-        if (cont && unit >= nUnits && poolBase >= nPool) {      // this generation is through: the paths it left behind form the next one
-            if (poolWrite == 0) {
-                cont = false;
-            } else {
-                nPool = poolWrite; poolBase = 0; poolWrite = 0;
-                __syncthreads();
-            }
+    }
+    __syncthreads();        // the claim's addends and pool entries are read next
+#ifdef RZ_PROF
+    const unsigned long long tce0_ = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- the end of the claim: which groups wait for parked paths?  Lane g counts group g's entries among those the claim has
+    // just written (a ballot per group and 64 entries), the groups that wait move to wait slots, the others are summed.
+    float* const slotsBase = addBase + (size_t)UNITS * 384;
+    int* const meta = K.wmeta + (size_t)blockIdx.x * 4 * K.nWaitSlots;
+    const int NS = K.nWaitSlots;
+    int myCnt = 0;
+    for (int e0 = 0; e0 < nPool; e0 += 64) {
+        const int e = e0 + lane;
+        const int ge = e < nPool ? (int)((W[BACK * WS + (size_t)(wpN + e)] >> 6) & 1023u) / nBatches : -1;
+        for (int g = 0; g < nGroups; ++g) {
+            const int n = mask_count(rz_ballot(ge == g));
+            if (lane == g) myCnt += n;
         }
-    } while (cont && ++guard < (1u << 20));
-    __syncthreads();
-    if (!claimDeferred) claim_ordered_sums<COUNT>(K, M, ci, addBase, nPix, ppw, nBatches);
+    }
+    const bool waiting = lane < nGroups && myCnt > 0;
+    const unsigned long long wm = rz_ballot(waiting);
+    int mySlot = 0;
+    if (waiting) {
+        mySlot = wmeta_load(meta + 2 * NS + (freeCount - 1 - __popcll(wm & ((1ull << lane) - 1ull))));
+        meta[mySlot] = M.group(ci, lane);
+        meta[NS + mySlot] = myCnt;
+    }
+    freeCount -= mask_count(wm);
+    // ... their addends move to their slots: a group's nBatches x 6 rows of 64 floats, one row per step
+    for (unsigned long long rest = wm; rest != 0ull; rest &= rest - 1ull) {
+        const int g = (int)__builtin_ctzll(rest);
+        const int sl = __builtin_amdgcn_readlane(mySlot, g);
+        const float* __restrict__ src = addBase + (size_t)g * nBatches * 384;
+        float* __restrict__ dst = slotsBase + (size_t)sl * K.slotFloats;
+#ifndef RZ_X_A3
+        for (int r = 0; r < nBatches * 6; ++r) dst[r * 64 + lane] = src[r * 64 + lane];
+#endif
+    }
+    // ... and their pool entries learn the slot and their batch within the group
+    for (int e0 = 0; e0 < nPool; e0 += 64) {
+        const int e = e0 + lane;
+        const unsigned back = e < nPool ? W[BACK * WS + (size_t)(wpN + e)] : 0u;
+        const int unit = (int)((back >> 6) & 1023u), ge = unit / nBatches;
+        const int eSlot = __shfl(mySlot, ge);       // (by every lane, see below)
+        if (e < nPool) {
+            W[BACK * WS + (size_t)(wpN + e)] = (back & 0xffff003fu) | ((unsigned)(unit - ge * nBatches) << 6);
+            W[(size_t)(RZ_GPOOL_FIELDS - 1) * WS + (size_t)(wpN + e)] = (unsigned)eSlot;
+        }
+    }
+    wpN += nPool;
+    // the groups that do not wait: their ordered sums, straight from the claim scratch
+#ifdef RZ_PROF
+    const unsigned long long tce1_ = __builtin_amdgcn_s_memtime();
+#endif
+    const int nPix = nGroups * ppw;
+    for (int p0 = 0; p0 < nPix; p0 += 21) {
+        const int q = lane / 3;
+        const int p = p0 + q;
+        const int g = (q < 21 && p < nPix) ? p / ppw : 0;
+        const int gCnt = __shfl(myCnt, g);          // (by every lane: a lane that sits a shuffle out reads as zero to the others)
+        const bool valid = q < 21 && p < nPix && gCnt == 0;
+        const int pin = p - g * ppw;
+        ordered_sum_pass<COUNT>(K, valid, addBase + (size_t)g * nBatches * 384, M.group(ci, g) * ppw + pin, pin * (spp >= 64 ? 0 : spp));
+    }
     if (COUNT) {
         tally_flush(K, c);
 #ifdef RZ_PROF
         unsigned long long* pr = reinterpret_cast<unsigned long long*>(K.counters + 1);
         for (int k = 0; k < 16; ++k) if (c.p[k]) atomicAdd(&pr[k], (unsigned long long)c.p[k]);
-        if (lane == 0) { for (int k = 0; k < 12; ++k) atomicAdd(&pr[19 + k], c.t[k]); for (int k = 12; k < 16; ++k) atomicAdd(&pr[108 + k], c.t[k]); }
+        c.t[16] += __builtin_amdgcn_s_memtime() - tce0_; c.t[18] += __builtin_amdgcn_s_memtime() - tce1_;
+        if (lane == 0) { for (int k = 0; k < 12; ++k) atomicAdd(&pr[19 + k], c.t[k]); for (int k = 12; k < 20; ++k) atomicAdd(&pr[108 + k], c.t[k]); }
         rz_prof_rounds(c, pr);
 #endif
     }
-    __syncthreads();        // the next claim overwrites the scratch
+    __syncthreads();        // the next claim overwrites the scratch; the pool pass reads what this one has written
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The pool a resident wave keeps ACROSS its claims (large opaque launches).
+// The pool a resident wave keeps ACROSS its claims.
 // A claim parks a few dozen paths; lanes can only refill from a list that is much longer than the wave is wide
-// (rz_trace.h: pool_trace).  So a wave no longer works a claim's parked paths off before its next claim: they collect in the
-// wave's own pool -- third, fourth ... segments side by side, a path carries its bounce -- the claims that wait for them
-// leave their addends in K.daddends, and when the pool holds K.wpoolChunk paths (and when the claims have run out) the wave
-// traces ALL of them together, shades them 64 at a time (the late part of the shader's bounce loop, FS:705-711 / 720-769:
-// sky and the end, or scatter and Russian roulette), writes the sky term of the paths that end to their samples' slots and
-// keeps the survivors, compacted in place (ballot + prefix popcount), for the next time.  When the claims have run out and
-// the pool has run dry, the wave replays the ordered sums of ITS claims that waited (a list linked through K.dflags).  Late work and coherent work so run side by side on a CU all through the
-// launch -- the late rays keep the texture-address unit busy (64 B per lane and step whatever the ray), the coherent ones
-// the issue slots -- and no queue is shared between waves: nothing to synchronise, nothing to wait for.
+// (rz_trace.h: pool_trace).  So a wave does not work a claim's parked paths off before its next claim: they collect in the
+// wave's own pool -- third, fourth ... segments side by side, a path carries its bounce -- and when the pool holds
+// K.wpoolChunk paths (and when the claims have run out, and when a claim finds too few free wait slots) the wave traces ALL of
+// them together, shades them 64 at a time (the late part of the shader's bounce loop, FS:705-711 / 720-769: sky and the end, or
+// scatter and Russian roulette), writes the sky term of the paths that end to their samples' places in their groups' wait
+// slots and keeps the survivors, compacted in place (ballot + prefix popcount), for the next time.  A group whose last path
+// has come back is summed at the end of the pass (slot_sums).  Late work and coherent work so run side by side on a CU all
+// through the launch -- the late rays keep the texture-address unit busy (64 B per lane and step whatever the ray), the
+// coherent ones the issue slots -- and no queue is shared between waves: nothing to synchronise, nothing to wait for.
 // A path's arithmetic does not depend on the lane, wave or moment that runs it: same bits as every other launch shape.
 template <bool COUNT, bool OVF>
-__device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restrict__ W, const size_t WS, const int n, const BlasStackT<OVF>& bstk) {
+__device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restrict__ W, const size_t WS, const int n, const BlasStackT<OVF>& bstk, int& freeCount) {
     using namespace poolf;
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
+    float* const slotsBase = K.wslots + (size_t)blockIdx.x * K.wslotStride + (size_t)K.claimUnits * 384;      // (behind the wave's claim scratch)
+    int* const meta = K.wmeta + (size_t)blockIdx.x * 4 * K.nWaitSlots;
+    const int NS = K.nWaitSlots;
     Tally c = {};
 #ifdef RZ_PROF
     const unsigned long long tl0_ = __builtin_amdgcn_s_memtime();
@@ -852,6 +889,7 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
     c.t[11] += (unsigned long long)n;               // queries in them
 #endif
     int write = 0;                                  // survivors so far: the write cursor trails the read cursor
+    int nReady = 0;                                 // groups whose last path has come back in this pass
     for (int sb = 0; sb < n; sb += 64) {
         const int sl = sb + lane;
         Path P;
@@ -860,7 +898,7 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
         P.addSky = mk3(0.0f, 0.0f, 0.0f);
         P.usedIor = 0;
         P.ior = 1.0f;
-        unsigned back = 0, dci = 0;
+        unsigned back = 0, wslot = 0;
         if (sl < n) {
             P.o = mk3(__uint_as_float(W[OX * WS + sl]), __uint_as_float(W[OY * WS + sl]), __uint_as_float(W[OZ * WS + sl]));
             P.d = mk3(__uint_as_float(W[DX * WS + sl]), __uint_as_float(W[DY * WS + sl]), __uint_as_float(W[DZ * WS + sl]));
@@ -869,7 +907,7 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
             P.seed.y = __uint_as_float(W[SEEDY * WS + sl]);
             P.samp = (int)W[SAMP * WS + sl];
             back = W[BACK * WS + sl];
-            dci = W[(size_t)(RZ_GPOOL_FIELDS - 1) * WS + sl];
+            wslot = W[(size_t)(RZ_GPOOL_FIELDS - 1) * WS + sl];
             P.bounce = (int)(back >> 16);
             P.color = mk3(0.0f, 0.0f, 0.0f);
             P.mode = MODE_SEGMENT;
@@ -888,11 +926,18 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
             advance<COUNT, false>(K, P, found, h, c);      // one segment: sky and the end, or scatter (no shadow queries after bounce 0)
         }
         const bool parked = P.mode != MODE_DONE;
-        if (sl < n && !parked) {           // the path has ended: its sky term (FS:709; zero when it ended by roulette or budget) goes to its sample's slot
-            float* const A = K.daddends + (size_t)dci * K.dClaimStride + (size_t)((back >> 6) & 1023u) * 384;
+        bool lastOne = false;
+        if (sl < n && !parked) {           // the path has ended: its sky term (FS:709; zero when it ended by roulette or budget) goes to its sample's place
+            float* const A = slotsBase + (size_t)wslot * K.slotFloats + (size_t)((back >> 6) & 1023u) * 384;
             const unsigned bl = back & 63u;
+#ifndef RZ_X_A1
             A[192 + bl] = P.addSky.x; A[256 + bl] = P.addSky.y; A[320 + bl] = P.addSky.z;
+#endif
+            lastOne = atomicSub(meta + NS + wslot, 1) == 1;        // the group's last path: it is summed at the end of this pass
         }
+        const unsigned long long lm = rz_ballot(lastOne);
+        if (lastOne) meta[3 * NS + nReady + __popcll(lm & below)] = (int)wslot;
+        nReady += mask_count(lm);
         const unsigned long long pm = rz_ballot(parked);
         if (parked) {
             const size_t d = (size_t)write + __popcll(pm & below);        // d <= sl: this round's slots have all been read
@@ -902,7 +947,7 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
             W[SEEDX * WS + d] = __float_as_uint(P.seed.x); W[SEEDY * WS + d] = __float_as_uint(P.seed.y);
             W[SAMP * WS + d] = (unsigned)P.samp;
             W[BACK * WS + d] = ((unsigned)P.bounce << 16) | (back & 0xffffu);
-            W[(size_t)(RZ_GPOOL_FIELDS - 1) * WS + d] = dci;
+            W[(size_t)(RZ_GPOOL_FIELDS - 1) * WS + d] = wslot;
         }
         write += mask_count(pm);
     }
@@ -910,12 +955,19 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
     c.t[9] += __builtin_amdgcn_s_memtime() - tl1_;      // the shade rounds
 #endif
     __syncthreads();
+#ifdef RZ_PROF
+    const unsigned long long tss0_ = __builtin_amdgcn_s_memtime();
+#endif
+    slot_sums<COUNT>(K, slotsBase, meta, nReady, freeCount);
+#ifdef RZ_PROF
+    c.t[17] += __builtin_amdgcn_s_memtime() - tss0_;
+#endif
     if (COUNT) {
         tally_flush(K, c);
 #ifdef RZ_PROF
         unsigned long long* pr = reinterpret_cast<unsigned long long*>(K.counters + 1);
         for (int k = 0; k < 16; ++k) if (c.p[k]) atomicAdd(&pr[k], (unsigned long long)c.p[k]);
-        if (lane == 0) { for (int k = 9; k < 12; ++k) atomicAdd(&pr[19 + k], c.t[k]); for (int k = 12; k < 16; ++k) atomicAdd(&pr[108 + k], c.t[k]); }
+        if (lane == 0) { for (int k = 9; k < 12; ++k) atomicAdd(&pr[19 + k], c.t[k]); for (int k = 12; k < 20; ++k) atomicAdd(&pr[108 + k], c.t[k]); }
         rz_prof_rounds(c, pr);
 #endif
     }
@@ -937,52 +989,43 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
         }
     }
     const ClaimMap M{nGroups, perClaim, nClaims, runShift};
-    int wpN = 0;                                // paths in this wave's cross-claim pool
-    int wpHead = 0;                             // ... and the newest of the claims that wait for them (index + 1; 0: none), linked through K.dflags
-    for (;;) {
-        unsigned ci = 0;
-        if ((threadIdx.x & 63) == 0) ci = atomicAdd(K.groupCounter, 1u);
-        ci = (unsigned)__builtin_amdgcn_readfirstlane((int)ci);
-        if (ci >= nClaims) break;               // every wave of the grid reaches this: the counter only grows
+    if constexpr (COMPACT > 1 && !GLASS) {
+        // every wait slot of this wave is free, nothing is parked
+        int* const meta = K.wmeta + (size_t)blockIdx.x * 4 * K.nWaitSlots;
+        if ((int)(threadIdx.x & 63) < K.nWaitSlots) meta[2 * K.nWaitSlots + (threadIdx.x & 63)] = (int)(threadIdx.x & 63);
+        __syncthreads();
+        int wpN = 0, freeCount = K.nWaitSlots;
+        const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + (threadIdx.x & 63),
+                                   OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + (threadIdx.x & 63) : nullptr, K.blasStackCap};
+        for (;;) {
+            unsigned ci = 0;
+            if ((threadIdx.x & 63) == 0) ci = atomicAdd(K.groupCounter, 1u);
+            ci = (unsigned)__builtin_amdgcn_readfirstlane((int)ci);
+            const bool more = ci < nClaims;         // every wave of the grid gets here with more == false in the end: the counter only grows
+            const int need = more ? M.units_of(ci) : 0;
+            // ONE place where the wave traces its pool: when it has filled up, when the next claim would find too few free wait
+            // slots, after every claim if the launch was told so (RZ_CROSS_CLAIM_POOL=0), and -- generation after generation --
+            // when the claims have run out.  Every pass moves its paths one bounce on and ends some of them: a path survives at
+            // most maxBounces - 1 scatters, and with an empty pool every slot is free (the bound is a backstop).
+            for (int guard = 0; wpN > 0 && (!more || wpN >= (int)K.wpoolChunk || freeCount < need || K.drainEachClaim != 0) && guard <= K.maxBounces + 1; ++guard)
+                wpN = pool_process<COUNT, OVF>(K, K.wpool + (size_t)blockIdx.x * K.wpoolStride * RZ_GPOOL_FIELDS, K.wpoolStride, wpN, bstk, freeCount);
+            if (!more || freeCount < need) break;   // (freeCount < need cannot be: see above -- but a claim must not run without its slots)
 #ifdef RZ_PROF
-        ++wl_claims;
+            ++wl_claims;
 #endif
-        if constexpr (COMPACT > 1 && !GLASS) {
-            render_claim_compact<COUNT, OVF, COMPACT>(K, M, ci, lds_raw, wpN, wpHead);
-            if (K.wpool != nullptr) {
-                // the wave's cross-claim pool has filled up: trace it -- again if so many paths survive that the next claim's
-                // could not be parked behind them (every pass moves its paths one bounce on: the bound is a backstop)
-                const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + (threadIdx.x & 63),
-                                           OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + (threadIdx.x & 63) : nullptr, K.blasStackCap};
-                for (int guard = 0; wpN >= (int)K.wpoolChunk && guard <= K.maxBounces; ++guard)
-                    wpN = pool_process<COUNT, OVF>(K, K.wpool + (size_t)blockIdx.x * K.wpoolStride * RZ_GPOOL_FIELDS, K.wpoolStride, wpN, bstk);
-            }
-        } else {
+            render_claim_compact<COUNT, OVF, COMPACT>(K, M, ci, lds_raw, wpN, freeCount);
+        }
+    } else {
+        for (;;) {
+            unsigned ci = 0;
+            if ((threadIdx.x & 63) == 0) ci = atomicAdd(K.groupCounter, 1u);
+            ci = (unsigned)__builtin_amdgcn_readfirstlane((int)ci);
+            if (ci >= nClaims) break;               // every wave of the grid reaches this: the counter only grows
+#ifdef RZ_PROF
+            ++wl_claims;
+#endif
             const int n = M.units_of(ci);
             for (int g = 0; g < n; ++g) render_samples_group<COUNT, GLASS, OVF, COMPACT == 1>(K, (unsigned)M.group(ci, g), lds_raw);
-        }
-    }
-    if constexpr (COMPACT > 1 && !GLASS) {
-        // the claims have run out: what is left in the wave's pool, generation after generation (a path survives at most
-        // maxBounces - 1 scatters: the bound is a backstop)
-        if (K.wpool != nullptr) {
-            const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + (threadIdx.x & 63),
-                                       OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + (threadIdx.x & 63) : nullptr, K.blasStackCap};
-            for (int guard = 0; wpN > 0 && guard <= K.maxBounces; ++guard)
-                wpN = pool_process<COUNT, OVF>(K, K.wpool + (size_t)blockIdx.x * K.wpoolStride * RZ_GPOOL_FIELDS, K.wpoolStride, wpN, bstk);
-            // every path of this wave's claims is back: the ordered sums of the claims that waited (their addends, sky terms
-            // included, are in K.daddends); the list cannot be longer than the claims of the launch
-            const int spp = K.spp, nBatches = (spp + 63) / 64, ppw = spp >= 64 ? 1 : 64 / spp;
-            unsigned walked = 0;
-            for (int h = wpHead; h != 0 && walked <= nClaims; ++walked) {
-                const unsigned ci = (unsigned)(h - 1);
-                claim_ordered_sums<COUNT>(K, M, ci, K.daddends + (size_t)ci * K.dClaimStride, M.units_of(ci) * ppw, ppw, nBatches);
-                // (read at device scope, past the scalar and vector L1 caches: the links of other waves' claims share cache lines with
-                //  this wave's, and a line cached before this wave stored its link would still hold the old word)
-                int nxt = 0;
-                if ((threadIdx.x & 63) == 0) nxt = __hip_atomic_load(K.dflags + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                h = __builtin_amdgcn_readfirstlane(nxt);
-            }
         }
     }
 #ifdef RZ_PROF
@@ -1108,11 +1151,11 @@ SamplesPlan plan_render_samples(int spp, int nSlots, bool glass) {
     const long long claims = p.perClaim ? (p.groups + p.perClaim - 1) / p.perClaim : p.groups;
     p.grid = p.perClaim ? std::min<long long>(claims, (long long)nCU * RZ_PERSIST_WAVES_PER_CU) : p.groups;
     p.nClaims = p.perClaim ? claims : 0;
-    // The waves of a large compacting launch keep their pool of parked paths ACROSS claims (pool_process): a claim's own pool
-    // holds a few dozen paths, and lanes can only refill from a list much longer than the wave is wide.
-    // RZ_CROSS_CLAIM_POOL=0/1 overrides (A/B aid).
-    p.crossClaimPool = p.compact && units >= RZ_CROSS_POOL_MIN_UNITS;
-    if (const char* e = std::getenv("RZ_CROSS_CLAIM_POOL")) p.crossClaimPool = p.compact && std::atoi(e) != 0;
+    // The waves of a compacting launch keep their pool of parked paths ACROSS claims (pool_process): a claim's own parked paths
+    // are a few dozen, and lanes can only refill from a list much longer than the wave is wide.  RZ_CROSS_CLAIM_POOL=0 makes
+    // every wave trace its pool to the end after each claim instead (round 2's per-claim pools; A/B and test aid).
+    p.drainEachClaim = false;
+    if (const char* e = std::getenv("RZ_CROSS_CLAIM_POOL")) p.drainEachClaim = std::atoi(e) == 0;
     // the shape of a claim (ClaimMap): one run of consecutive groups at 64 spp and more (a tile row; its parked paths are
     // neighbours), runs of RZ_CLAIM_RUN_SMALL_SPP groups from as many bands of the frame as it takes below (a claim of
     // consecutive 4-pixel groups inside a mesh costs many times the average claim, and the launch waits for the last one)
@@ -1133,7 +1176,7 @@ void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream
     const SamplesPlan plan = plan_render_samples(K.spp, K.nSlots, glass);
     const long long blocks = plan.groups, grid = plan.grid, perClaim = plan.perClaim;
     if (blocks <= 0) return;
-    const bool compact = plan.compact && K.claimScratch != nullptr;
+    const bool compact = plan.compact && K.wpool != nullptr;
     const size_t lds = (size_t)K.blasStackCap * 64 * sizeof(uint2) + (size_t)K.tlasStackCap * 64 * sizeof(int) + samples_lds_extra(glass, compact);
     const dim3 g((unsigned)grid), b(64);
     const unsigned nGroups = (unsigned)blocks;

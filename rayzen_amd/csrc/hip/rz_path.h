@@ -217,8 +217,54 @@ __device__ __forceinline__ void shade_light(const KParams& K, Path& P) {
     }
 }
 
+// The PREFIX of a sample that is about to read currentIor for the first time (its first transparent scatter, FS:723-746).
+// Everything a sample computes before that point -- the camera ray, the queries so far, the lighting of its first hit, shadow
+// walks through glass included -- does not depend on the currentIor it was started with; what follows does.  The speculating
+// launch (rz_kernels.hip: render_samples_group<GLASS>) computes a sample a second time when the value it guessed turns out wrong:
+// with the state at this point kept (19 dwords per lane in the resident wave's scratch, written once, read by the re-run) the
+// second version starts HERE, with the other currentIor, instead of at the camera.  [field][lane]: a field of the wave is one
+// 256-B line.  The counting instantiations keep the tallies of the prefix beside it.
+template <bool COUNT>
+__device__ __forceinline__ void snapshot_store(const KParams& K, const Path& P, const Tally& c) {
+    float* const S = K.snap + (size_t)blockIdx.x * K.snapStride + (threadIdx.x & 63);
+    S[0 * 64] = P.hp.x; S[1 * 64] = P.hp.y; S[2 * 64] = P.hp.z;
+    S[3 * 64] = P.hn.x; S[4 * 64] = P.hn.y; S[5 * 64] = P.hn.z;
+    S[6 * 64] = P.pdir.x; S[7 * 64] = P.pdir.y; S[8 * 64] = P.pdir.z;
+    S[9 * 64] = P.throughput.x; S[10 * 64] = P.throughput.y; S[11 * 64] = P.throughput.z;
+    S[12 * 64] = P.addLight.x; S[13 * 64] = P.addLight.y; S[14 * 64] = P.addLight.z;
+    S[15 * 64] = P.seed.x; S[16 * 64] = P.seed.y;
+    S[17 * 64] = __int_as_float(P.bounce); S[18 * 64] = __int_as_float(P.hmat);
+    if (COUNT) {        // (the scatter that is about to run has counted itself already: the resumed run counts it again)
+        const unsigned v[RZ_SNAP_TALLY] = {c.samples, c.traversals, c.tlas_nodes, c.tlas_leaf_indices, c.instances, c.blas_nodes, c.triangles,
+                                           c.materials, c.light_fetches, c.scatters - 1u, c.diffuse_scatters, c.hemi_draws, c.lit_lights, c.triangles_past_u};
+        for (int k = 0; k < RZ_SNAP_TALLY; ++k) S[(RZ_SNAP_FIELDS + k) * 64] = __uint_as_float(v[k]);
+    }
+}
+// ... and back: the path stands in front of the scatter again (the caller sets P.ior, P.samp and runs scatter<.., GLASS = true>)
+template <bool COUNT>
+__device__ __forceinline__ void snapshot_load(const KParams& K, Path& P, Tally& c) {
+    const float* const S = K.snap + (size_t)blockIdx.x * K.snapStride + (threadIdx.x & 63);
+    P.hp = mk3(S[0 * 64], S[1 * 64], S[2 * 64]);
+    P.hn = mk3(S[3 * 64], S[4 * 64], S[5 * 64]);
+    P.pdir = mk3(S[6 * 64], S[7 * 64], S[8 * 64]);
+    P.throughput = mk3(S[9 * 64], S[10 * 64], S[11 * 64]);
+    P.addLight = mk3(S[12 * 64], S[13 * 64], S[14 * 64]);
+    P.seed.x = S[15 * 64]; P.seed.y = S[16 * 64];
+    P.bounce = __float_as_int(S[17 * 64]); P.hmat = __float_as_int(S[18 * 64]);
+    P.addSky = mk3(0.0f, 0.0f, 0.0f);
+    P.usedIor = 0;
+    if (COUNT) {
+        unsigned v[RZ_SNAP_TALLY];
+        for (int k = 0; k < RZ_SNAP_TALLY; ++k) v[k] = __float_as_uint(S[(RZ_SNAP_FIELDS + k) * 64]);
+        c.samples = v[0]; c.traversals = v[1]; c.tlas_nodes = v[2]; c.tlas_leaf_indices = v[3]; c.instances = v[4]; c.blas_nodes = v[5];
+        c.triangles = v[6]; c.materials = v[7]; c.light_fetches = v[8]; c.scatters = v[9]; c.diffuse_scatters = v[10]; c.hemi_draws = v[11];
+        c.lit_lights = v[12]; c.triangles_past_u = v[13];
+    }
+}
+
 // FS:720-769: choose the next direction at the parked surface point and move on.
-template <bool COUNT, bool GLASS>
+// SNAP: keep the state in front of the sample's first transparent scatter (snapshot_store; only where K.snap is set).
+template <bool COUNT, bool GLASS, bool SNAP = false>
 __device__ __forceinline__ void scatter(const KParams& K, Path& P, Tally& c) {
     RZ_T0();
     if (COUNT) c.scatters += 1;
@@ -232,6 +278,9 @@ __device__ __forceinline__ void scatter(const KParams& K, Path& P, Tally& c) {
     const v3 hitNormal = P.hn;
     v3 dir = P.pdir;
     if (GLASS && M.transparency > 0.0f) {
+        if constexpr (SNAP) {
+            if (K.snap != nullptr && !P.usedIor) snapshot_store<COUNT>(K, P, c);
+        }
         P.usedIor = 1;
         const bool entering = dot(-dir, hitNormal) > 0.0f;
         const v3 N = entering ? hitNormal : -hitNormal;
@@ -286,15 +335,15 @@ __device__ __forceinline__ void scatter(const KParams& K, Path& P, Tally& c) {
 }
 
 // Lighting of the parked point is complete (or there are no lights): FS:717, then scatter.
-template <bool COUNT, bool GLASS>
+template <bool COUNT, bool GLASS, bool SNAP = false>
 __device__ __forceinline__ void finish_lighting(const KParams& K, Path& P, Tally& c) {
     P.addLight = P.throughput * P.lacc;
     P.color = P.color + P.addLight;
-    scatter<COUNT, GLASS>(K, P, c);
+    scatter<COUNT, GLASS, SNAP>(K, P, c);
 }
 
 // Advance a path by the result of the closest-hit query of its current ray.
-template <bool COUNT, bool GLASS = true>
+template <bool COUNT, bool GLASS = true, bool SNAP = false>
 __device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, const HitRec& h, Tally& c) {
     if (P.mode == MODE_SEGMENT) {
         if (!found) {   // FS:705-711
@@ -316,10 +365,10 @@ __device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, c
                          : mk3(0.05f * M.albedo[0], 0.05f * M.albedo[1], 0.05f * M.albedo[2]);
             P.li = 0;
             if (K.nLights > 0) { start_light<COUNT, GLASS>(K, P, c); return; }
-            finish_lighting<COUNT, GLASS>(K, P, c);
+            finish_lighting<COUNT, GLASS, SNAP>(K, P, c);
             return;
         }
-        scatter<COUNT, GLASS>(K, P, c);
+        scatter<COUNT, GLASS, SNAP>(K, P, c);
         return;
     }
     // MODE_SHADOW: the body of one iteration of FS:511-526
@@ -344,7 +393,7 @@ __device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, c
     if (lit) { RZ_T0(); if (COUNT) c.lit_lights += 1; shade_light<GLASS>(K, P); RZ_T1(c, 6); }
     P.li += 1;
     if (P.li < K.nLights) { start_light<COUNT, GLASS>(K, P, c); return; }
-    finish_lighting<COUNT, GLASS>(K, P, c);
+    finish_lighting<COUNT, GLASS, SNAP>(K, P, c);
 }
 
 }  // namespace rz

@@ -120,21 +120,26 @@ struct KParams {
     float camPos[3];
     int32_t blasOvfCap;     // entries per lane beyond the LDS window, kept in global memory (persistent launches only; else 0)
     uint2* blasOvf;         // [resident wave][blasOvfCap][64 lanes]
-    float* claimScratch;    // compacting launches (rz_kernels.hip: render_claim_compact): per resident wave, addends + survivor pool
-    uint32_t claimStride;   // dwords from one resident wave's scratch to the next (>= claim_scratch_dwords(units of the launch))
+    float* wslots;          // compacting launches (rz_kernels.hip: WAIT SLOTS): per resident wave, the claim scratch [claimUnits][6][64] floats, then nWaitSlots slots of slotFloats floats -- one group's addends [batch][6][64] each
+    uint32_t wslotStride;   // floats from one resident wave's scratch to the next (claimUnits x 384 + nWaitSlots x slotFloats)
     const DevTriN* triN;    // [triangle in leaf order] (rz_trace.h: trace_closest's epilogue)
     float hemi0[3];         // rz_path.h: hemisphere_local((+0, +0)), the local direction of every bounce-0 scatter (rz_hemi0_kernel, once per context)
     int32_t traceRoundCap;  // rz_trace.h: trace_spread's backstop -- more rounds than any walk of this TLAS takes (a lane enters an instance at most once per leaf entry)
     int32_t spreadTrace;    // 1: third and later path segments are traced lane by lane (rz_trace.h: trace_spread); 0: always the wave-cursor walk (a scheduling choice: same image)
-    // ---- the pool of parked paths a resident wave keeps ACROSS its claims (rz_kernels.hip: pool_process; null: every claim works
-    //      its own pool off before the next one, as small launches do)
+    // ---- the pool of parked paths a resident wave keeps ACROSS its claims (rz_kernels.hip: pool_process; compacting launches only)
     unsigned* wpool;        // [resident wave][RZ_GPOOL_FIELDS][wpoolStride]
     uint32_t wpoolStride;   // slots per field: wpoolChunk + the most one claim can park
     uint32_t wpoolChunk;    // the wave traces its pool when it holds at least this many paths (and at the end of the launch)
-    float* daddends;        // [claim][unit][6][64]: the addends of the claims whose pixels wait for parked paths
-    int32_t* dflags;        // [claim] the next older waiting claim of the same wave (index + 1; 0: none): the wave sums them at the end of the launch
-    uint32_t dClaimStride;  // floats per claim in daddends (units of a claim x 384)
+    int32_t* wmeta;         // [resident wave][4 nWaitSlots]: group index | outstanding paths | free stack | ready list of the wave's wait slots
+    uint32_t slotFloats;    // floats per wait slot: batches per pixel x 384
+    int32_t nWaitSlots;     // wait slots per resident wave (<= 64, >= twice the groups of a claim)
+    int32_t claimUnits;     // units of a claim (8 or 16: the kernel's COMPACT parameter)
+    int32_t drainEachClaim; // 1: a wave traces its pool to the end after every claim (RZ_CROSS_CLAIM_POOL=0: the per-claim pools of round 2; a scheduling choice, same image)
     int32_t regularBoxes;   // 1: every BLAS child box has min <= max on every axis (no NaN): the octant-specialised slab test may be used
+    // ---- transparent scenes, persistent launches: per resident wave, the state of each lane's sample in front of its first
+    //      transparent scatter (rz_path.h: snapshot_store), from which the sample's second version starts; null: re-runs start at the camera
+    float* snap;            // [resident wave][snapStride] floats
+    uint32_t snapStride;    // >= (RZ_SNAP_FIELDS + RZ_SNAP_TALLY) * 64
 };
 
 // Arguments of the device TLAS rebuild (rz_tlas_device.hip: rz_tlas_refit; filled in by rz_context.hip).
@@ -156,14 +161,12 @@ struct TlasWork {
 
 // How rz_render_samples is launched (rz_kernels.hip: plan_render_samples): groups of pixels, the grid, and the number
 // of groups a persistent wave claims per atomic (0: one workgroup per group).
-struct SamplesPlan { long long groups, grid; int perClaim; bool compact; int claimUnits; long long nClaims; int runShift; bool crossClaimPool; };   // claimUnits: 8 or 16 when compact; nClaims / runShift: rz_kernels.hip, ClaimMap
+struct SamplesPlan { long long groups, grid; int perClaim; bool compact; int claimUnits; long long nClaims; int runShift; bool drainEachClaim; };   // claimUnits: 8 or 16 when compact; nClaims / runShift: rz_kernels.hip, ClaimMap; drainEachClaim: KParams
 
-// Per resident wave of a compacting launch: the two addends of every sample of up to `units` (pixel, batch) units
-// [unit][6][64] floats, then the pool of parked paths [RZ_POOL_FIELDS][units * 64] dwords.  The kernel is instantiated for
-// claims of 8 and of 16 units (rz_kernels.hip: plan_render_samples picks by the size of the launch).
+// The kernel is instantiated for claims of 8 and of 16 units (rz_kernels.hip: plan_render_samples picks by the size of the launch).
 constexpr int RZ_CLAIM_UNITS_SMALL = 8, RZ_CLAIM_UNITS_LARGE = 16;
 constexpr int RZ_POOL_FIELDS = 23;      // the parked path (13), its query (8), the items of a B phase (2): rz_trace.h, namespace poolf
-constexpr int RZ_GPOOL_FIELDS = RZ_POOL_FIELDS + 1;     // a wave's cross-claim pool: ... + the claim a parked path belongs to (field 23)
-constexpr size_t claim_scratch_dwords(int units) { return (size_t)units * 6 * 64 + (size_t)RZ_POOL_FIELDS * units * 64; }
+constexpr int RZ_GPOOL_FIELDS = RZ_POOL_FIELDS + 1;     // a wave's pool: ... + the wait slot of the group a parked path belongs to (field 23)
+constexpr int RZ_SNAP_FIELDS = 19, RZ_SNAP_TALLY = 14;  // rz_path.h: snapshot_store -- a sample's state in front of its first transparent scatter (+ its tallies, counting launches)
 
 }  // namespace rz

@@ -48,7 +48,7 @@ struct Tally {          // per-thread counts of the REFERENCE algorithm's memory
     int rnd;                    // which closest-hit query of its path this lane is in (0 primary, 1-2 shadow, 3.. bounces), capped at 7
     unsigned rp[8][10];         // per query round: wave-execs / lanes of [0,1] descend steps [2,3] triangle tests [4,5] instance entries [6,7] uniform-pair steps [8,9] queries
     unsigned long long rt[8];   // per query round: wave cycles inside trace_closest (lane 0's clock)
-    unsigned long long t[16];   // ([4] / [9]: phase 1 / pool rounds of a compacting claim, [10] pool rounds, [11] paths in them)   wave cycles (s_memtime): [0] descend loops, [1] leaf phases, [2] whole BLAS walks; rz_path.h advance(): [3] sky, [4] hit bookkeeping, [5] start_light, [6] shade_light, [7] scatter, [8] of it the hemisphere direction, [9] shadow-step bookkeeping
+    unsigned long long t[20];   // ([16] the end-of-claim section of a compacting claim, [17] slot_sums inside pool_process, [18] the claim-end sums alone) ([4] / [9]: phase 1 / pool rounds of a compacting claim, [10] pool rounds, [11] paths in them)   wave cycles (s_memtime): [0] descend loops, [1] leaf phases, [2] whole BLAS walks; rz_path.h advance(): [3] sky, [4] hit bookkeeping, [5] start_light, [6] shade_light, [7] scatter, [8] of it the hemisphere direction, [9] shadow-step bookkeeping
 #endif
 };
 #ifdef RZ_PROF

@@ -223,7 +223,7 @@ class Renderer:
         """Test hook: how the last render call was launched (rz_launch_plan as a dict)."""
         lp = _lib.LaunchPlan()
         self._check(self._L.rz_debug_last_plan(self._c, C.byref(lp)), "rz_debug_last_plan")
-        return {n: int(getattr(lp, n)) for n, _ in _lib.LaunchPlan._fields_ if n != "reserved"}
+        return {n: int(getattr(lp, n)) for n, _ in _lib.LaunchPlan._fields_}
 
     def debug_read_layout(self, which):
         """Test hook: the device scene layout as raw bytes (0: DevPair[], 1: DevTri[])."""
