@@ -674,7 +674,7 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     //   * its claim scratch (the addends of the claim it is running, 1.5 KB per unit) and behind it its wait slots, one waiting
     //     group's addends (batches x 1.5 KB) each: at least twice the groups of a claim, 32 / batches by default (a claim that
     //     finds fewer free ones than it has groups makes the wave trace its pool first; RZ_WAIT_SLOTS overrides);
-    //   * 4 ints of bookkeeping per slot.
+    //   * 2 ints of bookkeeping per slot.
     // C2: 83 + 12 + 48 KB per wave, 0.59 GB for the grid (round 3: 3.7 GB, of which 3.2 GB an array of 1.5 KB per unit of the launch).
     // The scratch is optional: a launch that cannot have it (or is told so: RZ_DEBUG_NO_POOL_MEMORY=1, a test aid) runs the
     // plain persistent loop instead, same image.
@@ -696,7 +696,7 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
         if (nSlots >= groupsPerClaim && !(forceNo && std::atoi(forceNo) != 0) &&
             ensure_optional(c->dWavePools, (size_t)plan.grid * stride * RZ_GPOOL_FIELDS * sizeof(unsigned)) &&
             ensure_optional(c->dClaimScratch, (size_t)plan.grid * ((size_t)plan.claimUnits * 384 + nSlots * slotFloats + slotPad) * sizeof(float)) &&
-            ensure_optional(c->dDeferFlags, (size_t)plan.grid * 4 * nSlots * sizeof(int32_t))) {
+            ensure_optional(c->dDeferFlags, (size_t)plan.grid * 2 * nSlots * sizeof(int32_t))) {
             K.wpool = static_cast<unsigned*>(c->dWavePools.p);
             K.wpoolStride = (uint32_t)stride;
             K.wpoolChunk = (uint32_t)chunk;
@@ -710,7 +710,7 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
         }
     }
     c->lastGlobalPool = K.wpool != nullptr && K.drainEachClaim == 0;
-    c->lastScratchBytes = K.wpool ? (size_t)plan.grid * ((size_t)K.wpoolStride * RZ_GPOOL_FIELDS * 4 + (size_t)K.wslotStride * 4 + (size_t)16 * K.nWaitSlots) : 0;
+    c->lastScratchBytes = K.wpool ? (size_t)plan.grid * ((size_t)K.wpoolStride * RZ_GPOOL_FIELDS * 4 + (size_t)K.wslotStride * 4 + (size_t)8 * K.nWaitSlots) : 0;
     // transparent scenes, persistent launches: room for every resident wave's sample prefixes (19 + 14 dwords per lane, 34 MB for
     // the grid), so that a sample's second version starts at its first transparent scatter instead of at the camera.
     // RZ_GLASS_SNAPSHOT=0 switches it off (A/B aid: same image either way).

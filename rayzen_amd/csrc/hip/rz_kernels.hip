@@ -565,16 +565,29 @@ struct ClaimMap {
 //     ends paths; an empty pool means that every slot is free).
 // Scratch per resident wave on C2: pool 83 KB + claim scratch 12 KB + 32 slots x 1.5 KB = 143 KB, 0.59 GB for the grid, where
 // round 3 took 3.7 GB; C5: 0.9 GB where it took 25.
-// The meta block of a wave (ints): [0, NS) the launch-order index of the group in the slot | [NS, 2 NS) outstanding paths |
-// [2 NS, 3 NS) the free stack | [3 NS, 4 NS) the slots that became ready in the current pass.  It is read with vector loads at
-// workgroup scope (the scalar cache is not coherent with the wave's own stores), the one-wave workgroup's __syncthreads()
-// order the stores of a phase before the loads of the next.  Nothing per UNIT touches it: a dependent load per unit -- the first
-// version read the group's slot there -- cost the frame 10 % (one exposed memory round trip, 500 times per wave).
-__device__ __forceinline__ int wmeta_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// The meta block of a wave (ints): [0, NS) the launch-order index of the group in the slot | [NS, 2 NS) its outstanding paths
+// (-1: the slot is free).  Paths that end decrement with atomics that return nothing; the wave LOOKS at the counts once per pool
+// pass and once per claim that has groups to park -- lane s loads slot s's count past the L1 (the atomics act on the L2), a
+// ballot gives the free / the ready slots, a popcount of the lower lanes their ranks, ds_permute the k-th of them to lane k.
+// No free stack, no ready list, and above all no dependent memory round trip per shade pass or per unit: the first versions
+// had an atomic WITH return per pass (is this the group's last path?) and a slot look-up per unit, and each cost the frame
+// 5-10 % -- an exposed round trip drains every store the wave has in flight, 500 times per wave.
+__device__ __forceinline__ int wmeta_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// lane k <- the number of the k-th set lane of `m` (a scalar loop over its bits: slots are few and this runs once per pass)
+__device__ __forceinline__ int kth_set_lane(unsigned long long m) {
+    const int lane = threadIdx.x & 63;
+    int got = 0, k = 0;
+    for (unsigned long long rest = m; rest != 0ull; rest &= rest - 1ull, ++k)
+        if (lane == k) got = (int)__builtin_ctzll(rest);
+    return got;
+}
 
 // One pass of ordered sums: lane 3 q + ch replays the additions of channel ch of the pass's q-th pixel (q < 21) in sample
 // order, FS:717 then FS:709, sample after sample, from the group's addends A ([batch][6][64] floats); `slot` is the pixel's index
 // in launch order (its tile and place in the tile), `lane0` its first lane in a batch (spp < 64: pixel-in-group x spp).
+#ifndef RZ_SUM_UNROLL
+#define RZ_SUM_UNROLL 8
+#endif
 template <bool COUNT>
 __device__ __forceinline__ void ordered_sum_pass(const KParams& K, const bool valid, const float* __restrict__ A, const int slot, const int lane0) {
     const int lane = threadIdx.x & 63;
@@ -605,12 +618,21 @@ __device__ __forceinline__ void ordered_sum_pass(const KParams& K, const bool va
             const float* Sf = Lf + 192;
             const int cnt = spp >= 64 ? min(64, spp - b * 64) : spp;
             int k = 0;
+            // (the chain of additions waits for memory, not for the adder: RZ_SUM_UNROLL x 2 loads in flight per lane -- with 8 a
+            //  batch of 64 samples was eight exposed round trips, and a wave sums at the end of every claim)
+            for (; k + RZ_SUM_UNROLL <= cnt; k += RZ_SUM_UNROLL) {
+                float l[RZ_SUM_UNROLL], q8[RZ_SUM_UNROLL];
+#pragma unroll
+                for (int u = 0; u < RZ_SUM_UNROLL; ++u) { l[u] = Lf[k + u]; q8[u] = Sf[k + u]; }
+#pragma unroll
+                for (int u = 0; u < RZ_SUM_UNROLL; ++u) { chan = chan + l[u]; chan = chan + q8[u]; }   // FS:717, FS:709
+            }
             for (; k + 8 <= cnt; k += 8) {
                 float l[8], q8[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { l[u] = Lf[k + u]; q8[u] = Sf[k + u]; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { chan = chan + l[u]; chan = chan + q8[u]; }   // FS:717, FS:709
+                for (int u = 0; u < 8; ++u) { chan = chan + l[u]; chan = chan + q8[u]; }
             }
             for (; k < cnt; ++k) { chan = chan + Lf[k]; chan = chan + Sf[k]; }
         }
@@ -627,31 +649,27 @@ __device__ __forceinline__ void ordered_sum_pass(const KParams& K, const bool va
     }
 }
 
-// The ordered sums of the pixels of the `n` groups whose slots stand in the wave's ready list, 21 pixels per pass; then the slots
-// go back on the free stack.
+// The ordered sums of the pixels of the groups in the slots of `ready` (a lane mask over the slots), 21 pixels per pass; then
+// the slots are free again.
 template <bool COUNT>
-__device__ __forceinline__ void slot_sums(const KParams& K, const float* __restrict__ slotsBase, int* __restrict__ meta, const int n, int& freeCount) {
+__device__ __forceinline__ void slot_sums(const KParams& K, const float* __restrict__ slotsBase, int* __restrict__ meta, const unsigned long long ready, int& freeCount) {
     const int lane = threadIdx.x & 63;
     const int spp = K.spp, NS = K.nWaitSlots;
     const int ppw = spp >= 64 ? 1 : 64 / spp;
+    const int n = mask_count(ready);
     const int nPix = n * ppw;
+    const int slotOfRank = kth_set_lane(ready);                 // lane r: the r-th ready slot
+    const int gidxOfRank = lane < n ? wmeta_load(meta + slotOfRank) : 0;
     for (int p0 = 0; p0 < nPix; p0 += 21) {
         const int q = lane / 3;
         const int p = p0 + q;
         const bool valid = q < 21 && p < nPix;
-        const float* A = slotsBase;
-        int slot = 0, pin = 0;
-        if (valid) {
-            const int r = p / ppw;
-            pin = p - r * ppw;
-            const int sl = wmeta_load(meta + 3 * NS + r);
-            slot = wmeta_load(meta + sl) * ppw + pin;
-            A = slotsBase + (size_t)sl * K.slotFloats;
-        }
-        ordered_sum_pass<COUNT>(K, valid, A, slot, pin * (spp >= 64 ? 0 : spp));
+        const int r = valid ? p / ppw : 0;
+        const int pin = p - r * ppw;
+        const int sl = __shfl(slotOfRank, r), gidx = __shfl(gidxOfRank, r);       // (by every lane)
+        ordered_sum_pass<COUNT>(K, valid, slotsBase + (size_t)sl * K.slotFloats, gidx * ppw + pin, pin * (spp >= 64 ? 0 : spp));
     }
-    // the summed groups' slots are free again (n <= NS <= 64: one lane each)
-    if (lane < n) meta[2 * NS + freeCount + lane] = wmeta_load(meta + 3 * NS + lane);
+    if ((ready >> lane) & 1ull) meta[NS + lane] = -1;
     freeCount += n;
     __syncthreads();
 }
@@ -787,7 +805,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
     // ---- the end of the claim: which groups wait for parked paths?  Lane g counts group g's entries among those the claim has
     // just written (a ballot per group and 64 entries), the groups that wait move to wait slots, the others are summed.
     float* const slotsBase = addBase + (size_t)UNITS * 384;
-    int* const meta = K.wmeta + (size_t)blockIdx.x * 4 * K.nWaitSlots;
+    int* const meta = K.wmeta + (size_t)blockIdx.x * 2 * K.nWaitSlots;
     const int NS = K.nWaitSlots;
     int myCnt = 0;
     for (int e0 = 0; e0 < nPool; e0 += 64) {
@@ -801,21 +819,24 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
     const bool waiting = lane < nGroups && myCnt > 0;
     const unsigned long long wm = rz_ballot(waiting);
     int mySlot = 0;
-    if (waiting) {
-        mySlot = wmeta_load(meta + 2 * NS + (freeCount - 1 - __popcll(wm & ((1ull << lane) - 1ull))));
-        meta[mySlot] = M.group(ci, lane);
-        meta[NS + mySlot] = myCnt;
+    if (wm != 0ull) {
+        // the k-th waiting group takes the k-th free slot (count -1); the caller has seen to it that there are enough
+        const unsigned long long freeMask = rz_ballot(lane < NS && wmeta_load(meta + NS + (lane < NS ? lane : 0)) == -1);
+        const int freeOfRank = kth_set_lane(freeMask);
+        mySlot = __shfl(freeOfRank, __popcll(wm & ((1ull << lane) - 1ull)));     // (by every lane)
+        if (waiting) {
+            meta[mySlot] = M.group(ci, lane);
+            meta[NS + mySlot] = myCnt;
+        }
+        freeCount -= mask_count(wm);
     }
-    freeCount -= mask_count(wm);
     // ... their addends move to their slots: a group's nBatches x 6 rows of 64 floats, one row per step
     for (unsigned long long rest = wm; rest != 0ull; rest &= rest - 1ull) {
         const int g = (int)__builtin_ctzll(rest);
         const int sl = __builtin_amdgcn_readlane(mySlot, g);
         const float* __restrict__ src = addBase + (size_t)g * nBatches * 384;
         float* __restrict__ dst = slotsBase + (size_t)sl * K.slotFloats;
-#ifndef RZ_X_A3
         for (int r = 0; r < nBatches * 6; ++r) dst[r * 64 + lane] = src[r * 64 + lane];
-#endif
     }
     // ... and their pool entries learn the slot and their batch within the group
     for (int e0 = 0; e0 < nPool; e0 += 64) {
@@ -843,12 +864,14 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
         const int pin = p - g * ppw;
         ordered_sum_pass<COUNT>(K, valid, addBase + (size_t)g * nBatches * 384, M.group(ci, g) * ppw + pin, pin * (spp >= 64 ? 0 : spp));
     }
+#ifdef RZ_PROF
+    c.t[16] += __builtin_amdgcn_s_memtime() - tce0_; c.t[18] += __builtin_amdgcn_s_memtime() - tce1_;
+#endif
     if (COUNT) {
         tally_flush(K, c);
 #ifdef RZ_PROF
         unsigned long long* pr = reinterpret_cast<unsigned long long*>(K.counters + 1);
         for (int k = 0; k < 16; ++k) if (c.p[k]) atomicAdd(&pr[k], (unsigned long long)c.p[k]);
-        c.t[16] += __builtin_amdgcn_s_memtime() - tce0_; c.t[18] += __builtin_amdgcn_s_memtime() - tce1_;
         if (lane == 0) { for (int k = 0; k < 12; ++k) atomicAdd(&pr[19 + k], c.t[k]); for (int k = 12; k < 20; ++k) atomicAdd(&pr[108 + k], c.t[k]); }
         rz_prof_rounds(c, pr);
 #endif
@@ -875,7 +898,7 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
     float* const slotsBase = K.wslots + (size_t)blockIdx.x * K.wslotStride + (size_t)K.claimUnits * 384;      // (behind the wave's claim scratch)
-    int* const meta = K.wmeta + (size_t)blockIdx.x * 4 * K.nWaitSlots;
+    int* const meta = K.wmeta + (size_t)blockIdx.x * 2 * K.nWaitSlots;
     const int NS = K.nWaitSlots;
     Tally c = {};
 #ifdef RZ_PROF
@@ -889,7 +912,6 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
     c.t[11] += (unsigned long long)n;               // queries in them
 #endif
     int write = 0;                                  // survivors so far: the write cursor trails the read cursor
-    int nReady = 0;                                 // groups whose last path has come back in this pass
     for (int sb = 0; sb < n; sb += 64) {
         const int sl = sb + lane;
         Path P;
@@ -926,18 +948,12 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
             advance<COUNT, false>(K, P, found, h, c);      // one segment: sky and the end, or scatter (no shadow queries after bounce 0)
         }
         const bool parked = P.mode != MODE_DONE;
-        bool lastOne = false;
         if (sl < n && !parked) {           // the path has ended: its sky term (FS:709; zero when it ended by roulette or budget) goes to its sample's place
             float* const A = slotsBase + (size_t)wslot * K.slotFloats + (size_t)((back >> 6) & 1023u) * 384;
             const unsigned bl = back & 63u;
-#ifndef RZ_X_A1
             A[192 + bl] = P.addSky.x; A[256 + bl] = P.addSky.y; A[320 + bl] = P.addSky.z;
-#endif
-            lastOne = atomicSub(meta + NS + wslot, 1) == 1;        // the group's last path: it is summed at the end of this pass
+            atomicAdd(meta + NS + wslot, -1);      // (nothing comes back: the wave looks at the counts once, after the shade rounds)
         }
-        const unsigned long long lm = rz_ballot(lastOne);
-        if (lastOne) meta[3 * NS + nReady + __popcll(lm & below)] = (int)wslot;
-        nReady += mask_count(lm);
         const unsigned long long pm = rz_ballot(parked);
         if (parked) {
             const size_t d = (size_t)write + __popcll(pm & below);        // d <= sl: this round's slots have all been read
@@ -958,7 +974,9 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
 #ifdef RZ_PROF
     const unsigned long long tss0_ = __builtin_amdgcn_s_memtime();
 #endif
-    slot_sums<COUNT>(K, slotsBase, meta, nReady, freeCount);
+    // the groups whose last path has come back in this pass: count 0 (past the L1: the atomics act on the L2)
+    const unsigned long long ready = rz_ballot(lane < NS && wmeta_load(meta + NS + (lane < NS ? lane : 0)) == 0);
+    slot_sums<COUNT>(K, slotsBase, meta, ready, freeCount);
 #ifdef RZ_PROF
     c.t[17] += __builtin_amdgcn_s_memtime() - tss0_;
 #endif
@@ -990,9 +1008,9 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
     }
     const ClaimMap M{nGroups, perClaim, nClaims, runShift};
     if constexpr (COMPACT > 1 && !GLASS) {
-        // every wait slot of this wave is free, nothing is parked
-        int* const meta = K.wmeta + (size_t)blockIdx.x * 4 * K.nWaitSlots;
-        if ((int)(threadIdx.x & 63) < K.nWaitSlots) meta[2 * K.nWaitSlots + (threadIdx.x & 63)] = (int)(threadIdx.x & 63);
+        // every wait slot of this wave is free (count -1), nothing is parked
+        int* const meta = K.wmeta + (size_t)blockIdx.x * 2 * K.nWaitSlots;
+        if ((int)(threadIdx.x & 63) < K.nWaitSlots) meta[K.nWaitSlots + (threadIdx.x & 63)] = -1;
         __syncthreads();
         int wpN = 0, freeCount = K.nWaitSlots;
         const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + (threadIdx.x & 63),

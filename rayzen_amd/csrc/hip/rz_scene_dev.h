@@ -130,7 +130,7 @@ struct KParams {
     unsigned* wpool;        // [resident wave][RZ_GPOOL_FIELDS][wpoolStride]
     uint32_t wpoolStride;   // slots per field: wpoolChunk + the most one claim can park
     uint32_t wpoolChunk;    // the wave traces its pool when it holds at least this many paths (and at the end of the launch)
-    int32_t* wmeta;         // [resident wave][4 nWaitSlots]: group index | outstanding paths | free stack | ready list of the wave's wait slots
+    int32_t* wmeta;         // [resident wave][2 nWaitSlots]: the group in each of the wave's wait slots | its outstanding paths (-1: the slot is free)
     uint32_t slotFloats;    // floats per wait slot: batches per pixel x 384
     int32_t nWaitSlots;     // wait slots per resident wave (<= 64, >= twice the groups of a claim)
     int32_t claimUnits;     // units of a claim (8 or 16: the kernel's COMPACT parameter)
