@@ -47,6 +47,7 @@ struct BlasView {
     float rootMin[3] = {0, 0, 0}, rootMax[3] = {0, 0, 0};
     int depth = 1;
     bool empty = false;
+    bool mayGlass = true;       // a triangle of the view may use a transparent material (a scheduling hint for the kernels: DevInstance.flags bit 1)
 };
 
 constexpr int kNumBindings = 10;
@@ -83,6 +84,7 @@ struct rz_ctx {
     long long triNValid = -1;       // triangles dTriN holds normals for (-1: none; reset with the geometry)
     long long lastGrid = 0;         // workgroups of the last render launch (RZ_PROF: how many wave-log entries are valid)
     rz_launch_plan lastPlan{};      // rz_debug_last_plan
+    bool lastCompact = false;       // the last launch took compacting claims (rz_kernels.hip: render_claim_compact)
     bool lastGlobalPool = false;    // the last launch's waves kept their pools of parked paths across claims (rz_kernels.hip: pool_process)
     std::string err;
 
@@ -121,6 +123,7 @@ struct rz_ctx {
     int* relayoutPinned = nullptr;
     bool layoutOnDevice = false;        // dPairs / dTris were produced on the device (hPairs / hTris are empty)
     long long devPairsUsed = 0, devTrisUsed = 0;
+    bool matChangedSinceLayout = false; // materials were uploaded after the BLAS views were laid out: their per-view transparency hints are stale
     unsigned devTransparent = 0;       // device re-layout: bit 0 a transparent material is in use, bit 1 an irregular child box
     bool irregularBoxes = false;       // some BLAS child box has min > max or a NaN plane: the traversal keeps the generic slab test
     // rz_build_geometry: BLAS nodes / indices live in dRawNodes / dRawIdx; the host copies are fetched on demand
@@ -291,6 +294,7 @@ int build_view(rz_ctx* c, int nodeOff, int triOff, int gTriOff, BlasView& V) {
         // queue[i] is the i-th internal node in BFS order and its pair was pushed i-th: enc == i holds by construction
     }
     // gather triangles into leaf order
+    bool viewGlass = false;
     for (int s = 0; s < maxSlot; ++s) {
         const long long src = (long long)gTriOff + idx[triOff + s];
         if (src < 0 || src >= nTris) return fail(c, RZ_ERR_BAD_SCENE, "BLAS index %d -> triangle %lld outside the triangle array (%lld)", s, src, nTris);
@@ -300,10 +304,16 @@ int build_view(rz_ctx* c, int nodeOff, int triOff, int gTriOff, BlasView& V) {
         d.e1x = t.v1[0] - t.v0[0]; d.e1y = t.v1[1] - t.v0[1]; d.e1z = t.v1[2] - t.v0[2];   // FS:392
         d.e2x = t.v2[0] - t.v0[0]; d.e2y = t.v2[1] - t.v0[1]; d.e2z = t.v2[2] - t.v0[2];   // FS:393
         d.mat = t.materialIndex;
+        {   // (hint only: an index the material check will reject later counts as "may be transparent")
+            const int nMat_ = (int)hostCount<rz_material>(c, RZ_BIND_MATERIALS);
+            const rz_material* mats_ = hostArr<rz_material>(c, RZ_BIND_MATERIALS);
+            if (t.materialIndex < 0 || t.materialIndex >= nMat_ || !(mats_[t.materialIndex].transparency <= 0.0f)) viewGlass = true;
+        }
         d.src = (int32_t)src;
         if ((s & 1023) == 0) alloc_point(c);
         c->hTris.push_back(d);
     }
+    V.mayGlass = viewGlass;
     return RZ_OK;
 }
 
@@ -436,6 +446,7 @@ int device_view(rz_ctx* c, int nodeOff, int triOff, int gTriOff, BlasView& V) {
         root = hostArr<rz_bvh_node>(c, RZ_BIND_BLAS_NODES)[nodeOff];
     }
     RelayoutView R{};
+    unsigned viewFlags = 0;         // bit 0: a triangle of this view uses a transparent material, bit 1: an irregular child box
     R.nodeOff = nodeOff; R.triOff = triOff; R.gTriOff = gTriOff;
     R.pairBase = (int)c->devPairsUsed; R.triBase = (int)c->devTrisUsed;
     const int rc = relayout_view_device(static_cast<const rz_bvh_node*>(c->dRawNodes.p), nNodes, static_cast<const int32_t*>(c->dRawIdx.p), nIdx,
@@ -443,9 +454,11 @@ int device_view(rz_ctx* c, int nodeOff, int triOff, int gTriOff, BlasView& V) {
                                         (int)hostCount<rz_material>(c, RZ_BIND_MATERIALS), root, R,
                                         static_cast<DevPair*>(c->dPairs.p), (long long)(c->dPairs.cap / sizeof(DevPair)),
                                         static_cast<DevTri*>(c->dTris.p), (long long)(c->dTris.cap / sizeof(DevTri)), c->dRelayoutWs.p,
-                                        c->dRelayoutWs.cap, c->relayoutPinned, &c->devTransparent, c->stream);
+                                        c->dRelayoutWs.cap, c->relayoutPinned, &viewFlags, c->stream);
     if (rc < 0) return fail(c, RZ_ERR_HIP, "device re-layout: %s", hipGetErrorString((hipError_t)(-rc)));
     if (rc > 0) return 1;
+    c->devTransparent |= viewFlags;
+    V.mayGlass = (viewFlags & 1u) != 0;
     V.pairBase = R.pairBase; V.triBase = R.triBase; V.rootEnc = R.rootEnc; V.depth = R.depth; V.empty = R.empty != 0;
     std::memcpy(V.rootMin, R.rootMin, 12); std::memcpy(V.rootMax, R.rootMax, 12);
     c->devPairsUsed += R.nPairs; c->devTrisUsed += R.nSlots;
@@ -458,6 +471,9 @@ int finalize_body(rz_ctx* c) {
                   RZ_BIND_BLAS_NODES, RZ_BIND_BLAS_INDICES, RZ_BIND_INSTANCES})
         if (!c->present[b]) return fail(c, RZ_ERR_NOT_READY, "binding %d has not been uploaded", b);
 
+    // (the per-view "may hold transparent triangles" hints were taken from the materials of the moment the views were laid out)
+    if (c->geomDirty) c->matChangedSinceLayout = false;
+    else if (c->matDirty && !c->matChangedSinceLayout) { c->matChangedSinceLayout = true; c->instDirty = true; }
     // materials first: the device re-layout checks triangle material indices against them
     if (c->matDirty) {
         int rc = upload_vec(c, c->dMat, c->host[RZ_BIND_MATERIALS].data(), c->host[RZ_BIND_MATERIALS].size());
@@ -538,7 +554,10 @@ int finalize_body(rz_ctx* c) {
             D.rootEnc = V.rootEnc;
             D.pairBase = V.pairBase;
             D.triBase = V.triBase;
-            D.flags = V.empty ? 1 : 0;
+            // bit 0: never hit (empty BLAS).  bit 1: the view may hold transparent triangles -- a hint for the compacting claims
+            // (which rays not to park: rz_kernels.hip); when only the materials have changed since the views were laid out
+            // nobody knows any more, and every instance says "may"
+            D.flags = (V.empty ? 1 : 0) | ((V.mayGlass || c->matChangedSinceLayout) ? 2 : 0);
         }
         for (auto& kv : c->views) c->maxBlasDepth = std::max(c->maxBlasDepth, kv.second.depth);
         int rc = upload_vec(c, c->dInst, dev.data(), dev.size() * sizeof(DevInstance));
@@ -678,7 +697,7 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     // C2: 83 + 12 + 48 KB per wave, 0.59 GB for the grid (round 3: 3.7 GB, of which 3.2 GB an array of 1.5 KB per unit of the launch).
     // The scratch is optional: a launch that cannot have it (or is told so: RZ_DEBUG_NO_POOL_MEMORY=1, a test aid) runs the
     // plain persistent loop instead, same image.
-    K.wslots = nullptr; K.wslotStride = 0; K.slotFloats = 0; K.nWaitSlots = 0; K.wmeta = nullptr; K.drainEachClaim = 0; K.claimUnits = 0;
+    K.wslots = nullptr; K.wslotStride = 0; K.slotFloats = 0; K.nWaitSlots = 0; K.wmeta = nullptr; K.drainEachClaim = 0; K.claimUnits = 0; K.claimScratchFloats = 0;
     K.wpool = nullptr; K.wpoolStride = 0; K.wpoolChunk = 0;
     if (plan.compact && K.maxBounces < 65536) {
         long long chunk = RZ_WPOOL_CHUNK;
@@ -689,20 +708,25 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
         if (const char* e = std::getenv("RZ_WAIT_SLOTS")) nSlots = std::max(2 * groupsPerClaim, std::atoi(e));  // tuning / test aid
         nSlots = std::min(nSlots, 64);
         const size_t stride = (size_t)chunk + (size_t)plan.claimUnits * 64 + 64;
-        const size_t slotFloats = (size_t)nBatches * 384;
+        // (a group's addends; transparent scenes: + one row, the currentIor each pixel ends with)
+        const size_t slotFloats = (size_t)nBatches * 384 + (c->sceneHasTransparency ? 64 : 0);
+        const size_t claimScratchFloats = (size_t)groupsPerClaim * slotFloats;
+        bool snapOn = true;                 // transparent scenes resolve currentIor from the samples' snapshots: no snapshots, no claims
+        if (const char* e = std::getenv("RZ_GLASS_SNAPSHOT")) snapOn = std::atoi(e) != 0;
         size_t slotPad = 0;                                                                                      // floats between neighbouring waves' slot regions
         if (const char* e = std::getenv("RZ_SLOT_STRIDE_PAD")) slotPad = (size_t)std::max(0, std::atoi(e));     // tuning aid
         const char* forceNo = std::getenv("RZ_DEBUG_NO_POOL_MEMORY");      // test aid: as if the device had no room for it
-        if (nSlots >= groupsPerClaim && !(forceNo && std::atoi(forceNo) != 0) &&
+        if (nSlots >= groupsPerClaim && !(forceNo && std::atoi(forceNo) != 0) && (!c->sceneHasTransparency || snapOn) &&
             ensure_optional(c->dWavePools, (size_t)plan.grid * stride * RZ_GPOOL_FIELDS * sizeof(unsigned)) &&
-            ensure_optional(c->dClaimScratch, (size_t)plan.grid * ((size_t)plan.claimUnits * 384 + nSlots * slotFloats + slotPad) * sizeof(float)) &&
-            ensure_optional(c->dDeferFlags, (size_t)plan.grid * 2 * nSlots * sizeof(int32_t))) {
+            ensure_optional(c->dClaimScratch, (size_t)plan.grid * (claimScratchFloats + nSlots * slotFloats + slotPad) * sizeof(float)) &&
+            ensure_optional(c->dDeferFlags, (size_t)plan.grid * 4 * nSlots * sizeof(int32_t))) {
             K.wpool = static_cast<unsigned*>(c->dWavePools.p);
             K.wpoolStride = (uint32_t)stride;
             K.wpoolChunk = (uint32_t)chunk;
             K.wslots = static_cast<float*>(c->dClaimScratch.p);
-            K.wslotStride = (uint32_t)((size_t)plan.claimUnits * 384 + nSlots * slotFloats + slotPad);
+            K.wslotStride = (uint32_t)(claimScratchFloats + nSlots * slotFloats + slotPad);
             K.claimUnits = plan.claimUnits;
+            K.claimScratchFloats = (uint32_t)claimScratchFloats;
             K.slotFloats = (uint32_t)slotFloats;
             K.nWaitSlots = nSlots;
             K.wmeta = static_cast<int32_t*>(c->dDeferFlags.p);
@@ -710,7 +734,8 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
         }
     }
     c->lastGlobalPool = K.wpool != nullptr && K.drainEachClaim == 0;
-    c->lastScratchBytes = K.wpool ? (size_t)plan.grid * ((size_t)K.wpoolStride * RZ_GPOOL_FIELDS * 4 + (size_t)K.wslotStride * 4 + (size_t)8 * K.nWaitSlots) : 0;
+    c->lastCompact = K.wpool != nullptr;
+    c->lastScratchBytes = K.wpool ? (size_t)plan.grid * ((size_t)K.wpoolStride * RZ_GPOOL_FIELDS * 4 + (size_t)K.wslotStride * 4 + (size_t)16 * K.nWaitSlots) : 0;
     // transparent scenes, persistent launches: room for every resident wave's sample prefixes (19 + 14 dwords per lane, 34 MB for
     // the grid), so that a sample's second version starts at its first transparent scatter instead of at the camera.
     // RZ_GLASS_SNAPSHOT=0 switches it off (A/B aid: same image either way).
@@ -718,7 +743,7 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     if (c->sceneHasTransparency && plan.perClaim > 0) {
         bool on = true;
         if (const char* e = std::getenv("RZ_GLASS_SNAPSHOT")) on = std::atoi(e) != 0;
-        const size_t stride = (size_t)(RZ_SNAP_FIELDS + RZ_SNAP_TALLY) * 64;
+        const size_t stride = (size_t)(RZ_SNAP_FIELDS + RZ_SNAP_TALLY + RZ_GVER_ROWS) * 64;
         if (on) {
             rc = ensure(c, c->dSnap, (size_t)plan.grid * stride * sizeof(float));
             if (rc != RZ_OK) return rc;
@@ -807,7 +832,8 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     if (use_samples(c)) {
         rc = render_samples(c, K, counted, slot);
         if (rc != RZ_OK) return rc;
-        c->lastKernel = c->sceneHasTransparency ? "rz_render_samples<glass>" : (c->lastGlobalPool ? "rz_render_samples+pool" : "rz_render_samples");
+        c->lastKernel = c->sceneHasTransparency ? (c->lastCompact ? "rz_render_samples<glass>+pool" : "rz_render_samples<glass>")
+                                                : (c->lastGlobalPool ? "rz_render_samples+pool" : "rz_render_samples");
     } else {
         RZ_HIP(c, hipEventRecord(c->evStart[slot], c->stream));
         launch_render_pixels(K, counted, c->stream);

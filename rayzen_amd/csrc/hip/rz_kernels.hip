@@ -585,10 +585,11 @@ __device__ __forceinline__ int kth_set_lane(unsigned long long m) {
 // One pass of ordered sums: lane 3 q + ch replays the additions of channel ch of the pass's q-th pixel (q < 21) in sample
 // order, FS:717 then FS:709, sample after sample, from the group's addends A ([batch][6][64] floats); `slot` is the pixel's index
 // in launch order (its tile and place in the tile), `lane0` its first lane in a batch (spp < 64: pixel-in-group x spp).
+// GLASS: the currentIor the pixel ends with (FS:674) stands behind the addends, one row of 64, at its first lane.
 #ifndef RZ_SUM_UNROLL
 #define RZ_SUM_UNROLL 8
 #endif
-template <bool COUNT>
+template <bool COUNT, bool GLASS>
 __device__ __forceinline__ void ordered_sum_pass(const KParams& K, const bool valid, const float* __restrict__ A, const int slot, const int lane0) {
     const int lane = threadIdx.x & 63;
     const int spp = K.spp;
@@ -618,21 +619,12 @@ __device__ __forceinline__ void ordered_sum_pass(const KParams& K, const bool va
             const float* Sf = Lf + 192;
             const int cnt = spp >= 64 ? min(64, spp - b * 64) : spp;
             int k = 0;
-            // (the chain of additions waits for memory, not for the adder: RZ_SUM_UNROLL x 2 loads in flight per lane -- with 8 a
-            //  batch of 64 samples was eight exposed round trips, and a wave sums at the end of every claim)
             for (; k + RZ_SUM_UNROLL <= cnt; k += RZ_SUM_UNROLL) {
                 float l[RZ_SUM_UNROLL], q8[RZ_SUM_UNROLL];
 #pragma unroll
                 for (int u = 0; u < RZ_SUM_UNROLL; ++u) { l[u] = Lf[k + u]; q8[u] = Sf[k + u]; }
 #pragma unroll
                 for (int u = 0; u < RZ_SUM_UNROLL; ++u) { chan = chan + l[u]; chan = chan + q8[u]; }   // FS:717, FS:709
-            }
-            for (; k + 8 <= cnt; k += 8) {
-                float l[8], q8[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { l[u] = Lf[k + u]; q8[u] = Sf[k + u]; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { chan = chan + l[u]; chan = chan + q8[u]; }
             }
             for (; k < cnt; ++k) { chan = chan + Lf[k]; chan = chan + Sf[k]; }
         }
@@ -641,7 +633,7 @@ __device__ __forceinline__ void ordered_sum_pass(const KParams& K, const bool va
     const float cx = __shfl(chan, l0), cy = __shfl(chan, l0 + 1), cz = __shfl(chan, l0 + 2);
     if (inside && ch == 0) {
         K.accum[pix] = make_float4(cx, cy, cz, alpha + (float)spp);
-        K.ior[pix] = 1.0f;
+        K.ior[pix] = GLASS ? A[(size_t)nBatches * 384 + lane0] : 1.0f;
     }
     if (COUNT) {
         const unsigned long long im = rz_ballot(inside && ch == 0);
@@ -651,7 +643,7 @@ __device__ __forceinline__ void ordered_sum_pass(const KParams& K, const bool va
 
 // The ordered sums of the pixels of the groups in the slots of `ready` (a lane mask over the slots), 21 pixels per pass; then
 // the slots are free again.
-template <bool COUNT>
+template <bool COUNT, bool GLASS>
 __device__ __forceinline__ void slot_sums(const KParams& K, const float* __restrict__ slotsBase, int* __restrict__ meta, const unsigned long long ready, int& freeCount) {
     const int lane = threadIdx.x & 63;
     const int spp = K.spp, NS = K.nWaitSlots;
@@ -667,7 +659,7 @@ __device__ __forceinline__ void slot_sums(const KParams& K, const float* __restr
         const int r = valid ? p / ppw : 0;
         const int pin = p - r * ppw;
         const int sl = __shfl(slotOfRank, r), gidx = __shfl(gidxOfRank, r);       // (by every lane)
-        ordered_sum_pass<COUNT>(K, valid, slotsBase + (size_t)sl * K.slotFloats, gidx * ppw + pin, pin * (spp >= 64 ? 0 : spp));
+        ordered_sum_pass<COUNT, GLASS>(K, valid, slotsBase + (size_t)sl * K.slotFloats, gidx * ppw + pin, pin * (spp >= 64 ? 0 : spp));
     }
     if ((ready >> lane) & 1ull) meta[NS + lane] = -1;
     freeCount += n;
@@ -675,7 +667,145 @@ __device__ __forceinline__ void slot_sums(const KParams& K, const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// render_claim_compact: the opaque persistent path with RAY COMPACTION across the pixels of a claim
+// Transparent scenes on the compacting claims (round 4): FS:674's currentIor, resolved per UNIT.
+//
+// A pixel's samples are coupled through currentIor: a sample reads it where it scatters at a transparent surface (FS:727-742) and
+// may leave another value behind.  The claim runs a unit like an opaque one, every lane from the value its pixel has reached
+// (speculating that no earlier sample of the unit changes it).  If NO lane has read currentIor by the time the unit's paths are
+// through or stand in front of their third segment, the unit was clean: late paths are parked like an opaque scene's (a parked
+// path that later meets glass stops there and marks its group: the group is rendered again, below).  Otherwise the unit is
+// resolved HERE, in the wave: every lane runs to its end, and then the chain is walked -- sample after sample in the shader's
+// order, carrying currentIor: a sample that never read it has one result; one that did has one result per value it was run
+// from (two kept: currentIor is 1.0 or a material's ior); the first sample whose pixel's chain arrives with a value it was not
+// run from is run again, FROM ITS SNAPSHOT (rz_path.h: the state in front of its first transparent scatter), and with it,
+// speculatively, every later sample that lacks that value -- until every chain walks through.  Exactly the additions the
+// sequential shader makes, from exactly the currentIor it would have handed each sample.
+// The chain is walked on the SCALAR unit over the lanes that read currentIor (v_readlane of their keys and results): the
+// versions' bookkeeping is four registers per lane, their addends wait in the wave's scratch (K.snap, behind the snapshots) --
+// no LDS, so the whole BLAS stack stays there, unlike the group code's 5.4 KB of versions.
+// Which paths NOT to park in a transparent scene: a parked path that comes to a transparent scatter later costs its whole
+// group a second rendering (pool_process).  A ray can only reach glass through the world box of an instance that holds
+// transparent triangles (DevInstance.flags bit 1, a hint set at upload): the leaves of the pop-order TLAS list carry those
+// boxes, the list is short (RayZen's scenes: a handful of objects), and a path whose next ray passes such a box stays in the
+// wave for that segment -- if it does scatter at glass its unit is resolved in the wave, as it must be.  Long lists are not
+// walked (every path is parked: the image is the same either way, this only steers the schedule).
+#ifndef RZ_GLASS_BOX_MAX_DFS
+#define RZ_GLASS_BOX_MAX_DFS 64
+#endif
+__device__ __forceinline__ bool may_hit_glass(const KParams& K, const bool cand, const v3 o, const v3 d) {
+    if (K.nTlasDfs > RZ_GLASS_BOX_MAX_DFS || rz_ballot(cand) == 0ull) return false;
+    const v3 inv = rcp3(d);
+    bool hit = false;
+    for (int pos = 0; pos < K.nTlasDfs; ++pos) {
+        const f32x16 q = sload16(K.tlasDfs + pos);
+        if (__float_as_int(q[7]) <= 0) continue;                                        // internal or never expanding
+        if ((sload1(&K.instances[__float_as_int(q[9])].flags) & 2) == 0) continue;      // (a leaf of several instances speaks through its first: hint only)
+        float tmin;
+        hit = hit || slab(o, inv, q[0], q[1], q[2], q[4], q[5], q[6], tmin);
+    }
+    return cand && hit;
+}
+
+template <bool COUNT, bool OVF>
+__device__ __forceinline__ void glass_resolve_unit(const KParams& K, const BlasStackT<OVF>& bstk, Path& P, const bool mine, const int samp, const int lanePix,
+                                                   const float iorStart, float& iorEnd, Tally& c, const Tally& cStart) {
+    const int lane = threadIdx.x & 63;
+    float* const V = K.snap + (size_t)blockIdx.x * K.snapStride + (size_t)(RZ_SNAP_FIELDS + RZ_SNAP_TALLY) * 64 + lane;      // [version][6] rows, this lane's column
+    unsigned key0 = __float_as_uint(iorStart), key1 = 0u, out0 = 0u, out1 = 0u;     // per version: the currentIor it was run from / left behind (bit patterns: a NaN must equal itself)
+    int info0 = 0, info1 = 0;                                                       // bit 0: valid, bit 1: the sample read currentIor
+    int nextSlot = 0, chosen = 0;
+    unsigned want = __float_as_uint(iorStart);
+    bool running = mine;                // lanes whose version is being computed in this round
+    Tally tv0 = {}, tv1 = {};           // (counting launches: the tallies of each version's whole run)
+    Tally att = c;                      // ... of the run in progress: round 0 continues the run the claim has begun
+    if (COUNT) {
+        // what this lane's sample has tallied so far in this unit = c - cStart
+        att = {};
+        att.samples = c.samples - cStart.samples; att.traversals = c.traversals - cStart.traversals; att.tlas_nodes = c.tlas_nodes - cStart.tlas_nodes;
+        att.tlas_leaf_indices = c.tlas_leaf_indices - cStart.tlas_leaf_indices; att.instances = c.instances - cStart.instances;
+        att.blas_nodes = c.blas_nodes - cStart.blas_nodes; att.triangles = c.triangles - cStart.triangles; att.materials = c.materials - cStart.materials;
+        att.light_fetches = c.light_fetches - cStart.light_fetches; att.scatters = c.scatters - cStart.scatters;
+        att.diffuse_scatters = c.diffuse_scatters - cStart.diffuse_scatters; att.hemi_draws = c.hemi_draws - cStart.hemi_draws;
+        att.lit_lights = c.lit_lights - cStart.lit_lights; att.triangles_past_u = c.triangles_past_u - cStart.triangles_past_u;
+    }
+    iorEnd = iorStart;
+    // (every round gives each pixel's first blocked sample the version it lacks: at most 64 rounds per unit; the bound is a backstop)
+    for (int round = 0; round < 130; ++round) {
+        // ---- run the lanes of this round to their ends (round 0: the paths the claim has begun; later: second versions from snapshots)
+        bool anyRun = rz_ballot(P.mode != MODE_DONE) != 0ull;
+        while (anyRun) {
+            if (P.mode != MODE_DONE) {
+                HitRec h;
+                const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, COUNT ? att : c);
+                advance<COUNT, true, 1>(K, P, found, h, COUNT ? att : c);
+            }
+            anyRun = rz_ballot(P.mode != MODE_DONE) != 0ull;
+        }
+        if (running) {
+            const unsigned o = __float_as_uint(P.ior);
+            const int inf = 1 | (P.usedIor ? 2 : 0);
+            float* const R = V + (size_t)nextSlot * 6 * 64;
+            R[0] = P.addLight.x; R[64] = P.addLight.y; R[128] = P.addLight.z;
+            R[192] = P.addSky.x; R[256] = P.addSky.y; R[320] = P.addSky.z;
+            if (nextSlot == 0) { key0 = want; out0 = o; info0 = inf; if (COUNT) tv0 = att; }
+            else { key1 = want; out1 = o; info1 = inf; if (COUNT) tv1 = att; }
+            nextSlot ^= 1;
+        }
+        // ---- walk the chains: the lanes that read currentIor, in sample order, on the scalar unit
+        const unsigned long long touch = rz_ballot(mine && (((info0 | info1) & 2) != 0));
+        unsigned long long need = 0ull;
+        int curPix = -1;
+        unsigned cur = 0u;
+        bool blocked = false;
+        iorEnd = iorStart;
+        chosen = 0;
+        for (unsigned long long rest = touch; rest != 0ull; rest &= rest - 1ull) {
+            const int k = (int)__builtin_ctzll(rest);
+            const int pix = __builtin_amdgcn_readlane(lanePix, k);
+            if (pix != curPix) { curPix = pix; cur = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(iorStart), k); blocked = false; }
+            const int i0 = __builtin_amdgcn_readlane(info0, k), i1 = __builtin_amdgcn_readlane(info1, k);
+            const unsigned k0 = (unsigned)__builtin_amdgcn_readlane((int)key0, k), k1 = (unsigned)__builtin_amdgcn_readlane((int)key1, k);
+            const bool has0 = (i0 & 1) && k0 == cur, has1 = (i1 & 1) && k1 == cur;
+            if (!has0 && !has1) {
+                // this sample was not run from the value its chain arrives with: it is run again; the samples behind it are walked
+                // on the guess that it leaves the value alone
+                need |= 1ull << k;
+                if (lane == k) want = cur;
+                blocked = true;
+                continue;
+            }
+            const int v = has0 ? 0 : 1;
+            if (!blocked && lane == k) chosen = v;
+            cur = (unsigned)(v ? __builtin_amdgcn_readlane((int)out1, k) : __builtin_amdgcn_readlane((int)out0, k));
+            if (!blocked && lanePix == pix) iorEnd = __uint_as_float(cur);
+        }
+        if (need == 0ull) break;
+        // ---- the lanes that lack a version start it from their snapshots
+        running = ((need >> lane) & 1ull) != 0ull;
+        if (running) {
+            P.color = mk3(0.0f, 0.0f, 0.0f);
+            if (COUNT) att = {};
+            snapshot_load<COUNT>(K, P, COUNT ? att : c);
+            P.ior = __uint_as_float(want);
+            P.samp = samp;
+            scatter<COUNT, true, 0>(K, P, COUNT ? att : c);
+        }
+    }
+    // ---- every lane takes the version its chain chose (a sample that never read currentIor has the one)
+    if (mine) {
+        const float* const R = V + (size_t)chosen * 6 * 64;
+        P.addLight = mk3(R[0], R[64], R[128]);
+        P.addSky = mk3(R[192], R[256], R[320]);
+    }
+    if (COUNT) {
+        c = cStart;
+        if (mine) tally_add(c, chosen ? tv1 : tv0);
+    }
+    P.mode = MODE_DONE;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// render_claim_compact: the persistent path with RAY COMPACTION across the pixels of a claim
 // (north_star: "wavefront ballot / prefix-sum ray compaction for divergent bounces").
 // A claim is up to UNITS (pixel, 64-sample batch) units (spp < 64: groups of 64 / spp pixels).  The wave runs the units one
 // after the other, but a path that is about to trace its THIRD segment (bounce >= 2: 5 % of C2's paths, scattered over lanes
@@ -685,28 +815,38 @@ __device__ __forceinline__ void slot_sums(const KParams& K, const float* __restr
 // the wave's claim scratch; at the end of the claim the groups without a parked path are summed, one lane per (pixel, colour
 // channel): 24 lanes at once instead of 3 lanes eight times, and the others move to wait slots (above).  A path's arithmetic
 // does not depend on where it runs: same bits.
+// GLASS (the scene has a transparent material): units in which a sample reads currentIor are resolved in the wave
+// (glass_resolve_unit); nRedo > 0: the "claim" is nRedo groups off the wave's redo list -- groups one of whose pooled paths met
+// glass -- rendered again with every unit resolved in the wave.
 // All scratch is private to the resident wave (L1 / L2 hits); the __syncthreads() of the one-wave workgroup order its stores
 // before its loads.
-template <bool COUNT, bool OVF, int UNITS>
-__device__ __forceinline__ void render_claim_compact(const KParams& K, const ClaimMap M, const unsigned ci, unsigned char* lds_raw, int& wpN, int& freeCount) {
+template <bool COUNT, bool OVF, int UNITS, bool GLASS>
+__device__ __forceinline__ void render_claim_compact(const KParams& K, const ClaimMap M, const unsigned ci, const int nRedo, const int redoTop, unsigned char* lds_raw, int& wpN, int& freeCount) {
     using namespace poolf;
     const int lane = threadIdx.x & 63;
     const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + lane,
                                OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + lane : nullptr, K.blasStackCap};
-    float* const addBase = K.wslots + (size_t)blockIdx.x * K.wslotStride;         // the claim scratch: [unit][6][64]
+    float* const addBase = K.wslots + (size_t)blockIdx.x * K.wslotStride;         // the claim scratch: per group [batch][6][64] (+ 64: GLASS)
     unsigned* const W = K.wpool + (size_t)blockIdx.x * K.wpoolStride * RZ_GPOOL_FIELDS;
+    int* const meta = K.wmeta + (size_t)blockIdx.x * 4 * K.nWaitSlots;
+    const int NS = K.nWaitSlots;
     const size_t WS = K.wpoolStride;
+    const size_t GF = K.slotFloats;
     const int spp = K.spp;
     const int nBatches = (spp + 63) / 64;
+    const bool redo = GLASS && nRedo > 0;
     // a unit is one wave's worth of samples: a 64-sample batch of one pixel (spp >= 64), or all spp samples of each of the
     // ppw = 64 / spp pixels of a group (spp < 64: lane = pixel-in-group * spp + sample, the pixels a compact block of the tile)
     const int ppw = spp >= 64 ? 1 : 64 / spp;
-    const int nGroups = M.units_of(ci);               // <= UNITS / nBatches <= 16 by the launch plan; the caller has seen to it that as many wait slots are free
+    const int nGroups = redo ? nRedo : M.units_of(ci);   // <= UNITS / nBatches <= 16 by the launch plan; the caller has seen to it that as many wait slots are free
     const int nUnits = nGroups * nBatches;
     const int pixInUnit = spp >= 64 ? 0 : lane / spp; // (a lane with pixInUnit >= ppw is idle: spp need not divide 64)
     const int sampInUnit = spp >= 64 ? lane : lane - pixInUnit * spp;
+    // the g-th group of this claim, as its index in launch order (redo: the list's top nRedo entries)
+    auto group_of = [&](int g) -> int { return (GLASS && redo) ? wmeta_load(meta + 3 * NS + (redoTop - nRedo + g)) : M.group(ci, g); };
     int nPool = 0;                                            // wave-uniform: paths this claim has parked so far
     int tileCached = -1, tileX = 0, tileY = 0;                // wave-uniform: the tile of the current unit
+    float iorCarry = 1.0f;                                    // GLASS: the currentIor this lane's pixel has reached (carried from batch to batch)
     Tally c = {};
     for (int unit = 0; unit < nUnits; ++unit) {
         Path P;         // (per unit: nothing of a path lives across units)
@@ -718,9 +858,13 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
         P.addSky = mk3(0.0f, 0.0f, 0.0f);
         P.usedIor = 0;
         P.ior = 1.0f;
+        const int g = nBatches == 1 ? unit : unit / nBatches, b = unit - g * nBatches;
+        bool mine = false;
+        float iorStart = 1.0f;
+        Tally cStart = {};
+        if (COUNT && GLASS) cStart = c;
         {
-            const int g = nBatches == 1 ? unit : unit / nBatches, b = unit - g * nBatches;
-            const int slot = M.group(ci, g) * ppw + pixInUnit;
+            const int slot = group_of(g) * ppw + pixInUnit;
             const int localTile = slot >> 6, l = slot & 63;
             int px, py;
             if (spp >= 64 || (64 % ppw) == 0) {
@@ -739,7 +883,13 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
                 px = tx * RZ_TILE_W + slot_x(l, true); py = ty * RZ_TILE_H + slot_y(l, true);
             }
             const int s = b * 64 + sampInUnit;
-            if (pixInUnit < ppw && slot < K.nSlots && px < K.width && py < K.height && s < spp) {
+            const bool pixInside = pixInUnit < ppw && slot < K.nSlots && px < K.width && py < K.height;
+            if constexpr (GLASS) {
+                // FS:674: currentIor enters the pixel's first sample of this launch as the last launch left it (sample_base > 0) or as 1
+                iorStart = b == 0 ? ((K.sampleBase != 0 && pixInside) ? K.ior[(size_t)py * K.width + px] : 1.0f) : iorCarry;
+            }
+            if (pixInside && s < spp) {
+                mine = true;
                 const float fragx = (float)px + 0.5f, fragy = (float)py + 0.5f;
                 P.uv.x = fragx / (float)K.width;
                 P.uv.y = fragy / (float)K.height;
@@ -747,10 +897,12 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
                 P.color = mk3(0.0f, 0.0f, 0.0f);
                 P.samp = K.sampleBase + s;
                 begin_sample<COUNT>(K, P, c);
+                if constexpr (GLASS) P.ior = iorStart;
             }
         }
         // A unit's paths run until they finish or stand in front of their third segment (bounce >= 2).
         // (one exit, at the end of the body: see blas_walk)
+        // (transparent scenes: ... unless that segment's ray passes the box of an instance with glass in it -- may_hit_glass)
         bool run = P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= RZ_PARK_BOUNCE);
         bool anyRun = rz_ballot(run) != 0ull;
 #ifdef RZ_PROF
@@ -767,18 +919,29 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
 #ifdef RZ_PROF
                 c.rt[c.rnd & 7] += __builtin_amdgcn_s_memtime() - tq0_;
 #endif
-                advance<COUNT, false>(K, P, found, h, c);
+                advance<COUNT, GLASS, GLASS ? 1 : 0>(K, P, found, h, c);
             }
 #ifdef RZ_PROF
             if (c.rnd < 7) ++c.rnd;
 #endif
-            run = P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= RZ_PARK_BOUNCE);
+            const bool late = P.mode == MODE_SEGMENT && P.bounce >= RZ_PARK_BOUNCE;
+            run = P.mode != MODE_DONE && !late;
+            if constexpr (GLASS) run = run || may_hit_glass(K, late, P.o, P.d);
             anyRun = rz_ballot(run) != 0ull;
+        }
+        if constexpr (GLASS) {
+            // did a sample of this unit read currentIor?  Then (and in counting launches, whose tallies must be those of the final
+            // versions alone, and when a group is rendered again) the unit is resolved here; otherwise it was clean.
+            float iorEnd = iorStart;
+            if (COUNT || redo || rz_ballot(P.usedIor != 0) != 0ull)
+                glass_resolve_unit<COUNT, OVF>(K, bstk, P, mine, K.sampleBase + b * 64 + sampInUnit, pixInUnit, iorStart, iorEnd, c, cStart);
+            iorCarry = iorEnd;
+            if (b == nBatches - 1) addBase[(size_t)g * GF + (size_t)nBatches * 384 + lane] = iorEnd;       // (read at this lane's pixel's first lane by the sums)
         }
         const bool parked = P.mode != MODE_DONE;
         const unsigned long long pm = rz_ballot(parked);
         {
-            float* const A = addBase + (size_t)unit * 384;
+            float* const A = addBase + (size_t)g * GF + (size_t)b * 384;
             A[lane] = P.addLight.x; A[64 + lane] = P.addLight.y; A[128 + lane] = P.addLight.z;        // FS:717
             A[192 + lane] = P.addSky.x; A[256 + lane] = P.addSky.y; A[320 + lane] = P.addSky.z;       // FS:709 (parked: still 0)
         }
@@ -804,9 +967,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
 #endif
     // ---- the end of the claim: which groups wait for parked paths?  Lane g counts group g's entries among those the claim has
     // just written (a ballot per group and 64 entries), the groups that wait move to wait slots, the others are summed.
-    float* const slotsBase = addBase + (size_t)UNITS * 384;
-    int* const meta = K.wmeta + (size_t)blockIdx.x * 2 * K.nWaitSlots;
-    const int NS = K.nWaitSlots;
+    float* const slotsBase = addBase + K.claimScratchFloats;
     int myCnt = 0;
     for (int e0 = 0; e0 < nPool; e0 += 64) {
         const int e = e0 + lane;
@@ -825,25 +986,26 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
         const int freeOfRank = kth_set_lane(freeMask);
         mySlot = __shfl(freeOfRank, __popcll(wm & ((1ull << lane) - 1ull)));     // (by every lane)
         if (waiting) {
-            meta[mySlot] = M.group(ci, lane);
+            meta[mySlot] = group_of(lane);
             meta[NS + mySlot] = myCnt;
+            if (GLASS) meta[2 * NS + mySlot] = 0;
         }
         freeCount -= mask_count(wm);
     }
-    // ... their addends move to their slots: a group's nBatches x 6 rows of 64 floats, one row per step
+    // ... their addends move to their slots: a group's rows of 64 floats, one row per step
     for (unsigned long long rest = wm; rest != 0ull; rest &= rest - 1ull) {
         const int g = (int)__builtin_ctzll(rest);
         const int sl = __builtin_amdgcn_readlane(mySlot, g);
-        const float* __restrict__ src = addBase + (size_t)g * nBatches * 384;
-        float* __restrict__ dst = slotsBase + (size_t)sl * K.slotFloats;
-        for (int r = 0; r < nBatches * 6; ++r) dst[r * 64 + lane] = src[r * 64 + lane];
+        const float* __restrict__ src = addBase + (size_t)g * GF;
+        float* __restrict__ dst = slotsBase + (size_t)sl * GF;
+        for (int r = 0; r < (int)(GF >> 6); ++r) dst[r * 64 + lane] = src[r * 64 + lane];
     }
     // ... and their pool entries learn the slot and their batch within the group
     for (int e0 = 0; e0 < nPool; e0 += 64) {
         const int e = e0 + lane;
         const unsigned back = e < nPool ? W[BACK * WS + (size_t)(wpN + e)] : 0u;
         const int unit = (int)((back >> 6) & 1023u), ge = unit / nBatches;
-        const int eSlot = __shfl(mySlot, ge);       // (by every lane, see below)
+        const int eSlot = __shfl(mySlot, ge);       // (by every lane: a lane that sits a shuffle out reads as zero to the others)
         if (e < nPool) {
             W[BACK * WS + (size_t)(wpN + e)] = (back & 0xffff003fu) | ((unsigned)(unit - ge * nBatches) << 6);
             W[(size_t)(RZ_GPOOL_FIELDS - 1) * WS + (size_t)(wpN + e)] = (unsigned)eSlot;
@@ -859,10 +1021,10 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
         const int q = lane / 3;
         const int p = p0 + q;
         const int g = (q < 21 && p < nPix) ? p / ppw : 0;
-        const int gCnt = __shfl(myCnt, g);          // (by every lane: a lane that sits a shuffle out reads as zero to the others)
+        const int gCnt = __shfl(myCnt, g);          // (by every lane)
         const bool valid = q < 21 && p < nPix && gCnt == 0;
         const int pin = p - g * ppw;
-        ordered_sum_pass<COUNT>(K, valid, addBase + (size_t)g * nBatches * 384, M.group(ci, g) * ppw + pin, pin * (spp >= 64 ? 0 : spp));
+        ordered_sum_pass<COUNT, GLASS>(K, valid, addBase + (size_t)g * GF, group_of(g) * ppw + pin, pin * (spp >= 64 ? 0 : spp));
     }
 #ifdef RZ_PROF
     c.t[16] += __builtin_amdgcn_s_memtime() - tce0_; c.t[18] += __builtin_amdgcn_s_memtime() - tce1_;
@@ -892,13 +1054,16 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
 // through the launch -- the late rays keep the texture-address unit busy (64 B per lane and step whatever the ray), the
 // coherent ones the issue slots -- and no queue is shared between waves: nothing to synchronise, nothing to wait for.
 // A path's arithmetic does not depend on the lane, wave or moment that runs it: same bits as every other launch shape.
-template <bool COUNT, bool OVF>
-__device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restrict__ W, const size_t WS, const int n, const BlasStackT<OVF>& bstk, int& freeCount) {
+// GLASS: a pooled path belongs to a unit in which no sample had read currentIor; if IT comes to a transparent scatter it stops
+// there (it may not read a value that an earlier sample of its pixel, still in the pool, could change) and marks its group,
+// which is put on the wave's redo list instead of being summed when its last path is back.
+template <bool COUNT, bool OVF, bool GLASS>
+__device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restrict__ W, const size_t WS, const int n, const BlasStackT<OVF>& bstk, int& freeCount, int& redoCount) {
     using namespace poolf;
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
-    float* const slotsBase = K.wslots + (size_t)blockIdx.x * K.wslotStride + (size_t)K.claimUnits * 384;      // (behind the wave's claim scratch)
-    int* const meta = K.wmeta + (size_t)blockIdx.x * 2 * K.nWaitSlots;
+    float* const slotsBase = K.wslots + (size_t)blockIdx.x * K.wslotStride + K.claimScratchFloats;      // (behind the wave's claim scratch)
+    int* const meta = K.wmeta + (size_t)blockIdx.x * 4 * K.nWaitSlots;
     const int NS = K.nWaitSlots;
     Tally c = {};
 #ifdef RZ_PROF
@@ -945,13 +1110,14 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
                 h.mat = __float_as_int(nm.w);
                 h.inst = qInst;
             }
-            advance<COUNT, false>(K, P, found, h, c);      // one segment: sky and the end, or scatter (no shadow queries after bounce 0)
+            advance<COUNT, GLASS, GLASS ? 2 : 0>(K, P, found, h, c);      // one segment: sky and the end, or scatter (no shadow queries after bounce 0)
         }
         const bool parked = P.mode != MODE_DONE;
         if (sl < n && !parked) {           // the path has ended: its sky term (FS:709; zero when it ended by roulette or budget) goes to its sample's place
             float* const A = slotsBase + (size_t)wslot * K.slotFloats + (size_t)((back >> 6) & 1023u) * 384;
             const unsigned bl = back & 63u;
             A[192 + bl] = P.addSky.x; A[256 + bl] = P.addSky.y; A[320 + bl] = P.addSky.z;
+            if (GLASS && P.usedIor) meta[2 * NS + wslot] = 1;       // it stopped in front of a transparent scatter: its group is rendered again
             atomicAdd(meta + NS + wslot, -1);      // (nothing comes back: the wave looks at the counts once, after the shade rounds)
         }
         const unsigned long long pm = rz_ballot(parked);
@@ -975,8 +1141,21 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
     const unsigned long long tss0_ = __builtin_amdgcn_s_memtime();
 #endif
     // the groups whose last path has come back in this pass: count 0 (past the L1: the atomics act on the L2)
-    const unsigned long long ready = rz_ballot(lane < NS && wmeta_load(meta + NS + (lane < NS ? lane : 0)) == 0);
-    slot_sums<COUNT>(K, slotsBase, meta, ready, freeCount);
+    unsigned long long ready = rz_ballot(lane < NS && wmeta_load(meta + NS + (lane < NS ? lane : 0)) == 0);
+    if constexpr (GLASS) {
+        // ... of them, the groups a path of which met glass: onto the redo list (the wave renders them again before anything
+        // else: rz_render_samples), their slots are free
+        const unsigned long long dirty = ready & rz_ballot(lane < NS && wmeta_load(meta + 2 * NS + (lane < NS ? lane : 0)) == 1);
+        if ((dirty >> lane) & 1ull) {
+            meta[3 * NS + redoCount + __popcll(dirty & below)] = wmeta_load(meta + lane);
+            meta[2 * NS + lane] = 0;
+            meta[NS + lane] = -1;
+        }
+        redoCount += mask_count(dirty);
+        freeCount += mask_count(dirty);
+        ready &= ~dirty;
+    }
+    slot_sums<COUNT, GLASS>(K, slotsBase, meta, ready, freeCount);
 #ifdef RZ_PROF
     c.t[17] += __builtin_amdgcn_s_memtime() - tss0_;
 #endif
@@ -1000,38 +1179,50 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
     const unsigned long long wl_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned wl_claims = 0;
 #endif
-    if constexpr (COMPACT <= 1 || GLASS) {      // (a compacting launch always claims: its instantiations carry no copy of the group code)
+    if constexpr (COMPACT <= 1) {               // (a compacting launch always claims: its instantiations carry no copy of the group code)
         if (perClaim == 0) {                    // one workgroup per pixel group (small launches, spp < 64)
             render_samples_group<COUNT, GLASS, OVF, COMPACT == 1>(K, blockIdx.x, lds_raw);
             return;
         }
     }
     const ClaimMap M{nGroups, perClaim, nClaims, runShift};
-    if constexpr (COMPACT > 1 && !GLASS) {
-        // every wait slot of this wave is free (count -1), nothing is parked
-        int* const meta = K.wmeta + (size_t)blockIdx.x * 2 * K.nWaitSlots;
+    if constexpr (COMPACT > 1) {
+        // every wait slot of this wave is free (count -1), nothing is parked, nothing is to be rendered again
+        int* const meta = K.wmeta + (size_t)blockIdx.x * 4 * K.nWaitSlots;
         if ((int)(threadIdx.x & 63) < K.nWaitSlots) meta[K.nWaitSlots + (threadIdx.x & 63)] = -1;
         __syncthreads();
-        int wpN = 0, freeCount = K.nWaitSlots;
+        int wpN = 0, freeCount = K.nWaitSlots, redoCount = 0;
         const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + (threadIdx.x & 63),
                                    OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + (threadIdx.x & 63) : nullptr, K.blasStackCap};
-        for (;;) {
+        // (every iteration renders a claim or some redo groups, or ends the wave: the bound is a backstop)
+        for (unsigned long long iter = 0; iter < (1ull << 40); ++iter) {
+            const bool redo = GLASS && redoCount > 0;
             unsigned ci = 0;
-            if ((threadIdx.x & 63) == 0) ci = atomicAdd(K.groupCounter, 1u);
-            ci = (unsigned)__builtin_amdgcn_readfirstlane((int)ci);
-            const bool more = ci < nClaims;         // every wave of the grid gets here with more == false in the end: the counter only grows
-            const int need = more ? M.units_of(ci) : 0;
-            // ONE place where the wave traces its pool: when it has filled up, when the next claim would find too few free wait
-            // slots, after every claim if the launch was told so (RZ_CROSS_CLAIM_POOL=0), and -- generation after generation --
-            // when the claims have run out.  Every pass moves its paths one bounce on and ends some of them: a path survives at
-            // most maxBounces - 1 scatters, and with an empty pool every slot is free (the bound is a backstop).
-            for (int guard = 0; wpN > 0 && (!more || wpN >= (int)K.wpoolChunk || freeCount < need || K.drainEachClaim != 0) && guard <= K.maxBounces + 1; ++guard)
-                wpN = pool_process<COUNT, OVF>(K, K.wpool + (size_t)blockIdx.x * K.wpoolStride * RZ_GPOOL_FIELDS, K.wpoolStride, wpN, bstk, freeCount);
-            if (!more || freeCount < need) break;   // (freeCount < need cannot be: see above -- but a claim must not run without its slots)
+            int nRedo = 0;
+            if (redo) {
+                nRedo = redoCount < (int)perClaim ? redoCount : (int)perClaim;      // a transparent scene's groups to render again come first
+            } else {
+                if ((threadIdx.x & 63) == 0) ci = atomicAdd(K.groupCounter, 1u);
+                ci = (unsigned)__builtin_amdgcn_readfirstlane((int)ci);
+                const bool more = ci < nClaims;         // every wave of the grid gets here with more == false in the end: the counter only grows
+                const int need = more ? M.units_of(ci) : 0;
+                // ONE place where the wave traces its pool: when it has filled up, when the next claim would find too few free wait
+                // slots, after every claim if the launch was told so (RZ_CROSS_CLAIM_POOL=0), and -- generation after generation --
+                // when the claims have run out.  Every pass moves its paths one bounce on and ends some of them: a path survives at
+                // most maxBounces - 1 scatters, and with an empty pool every slot is free (the bound is a backstop).
+                for (int guard = 0; wpN > 0 && (!more || wpN >= (int)K.wpoolChunk || freeCount < need || K.drainEachClaim != 0) && guard <= K.maxBounces + 1; ++guard)
+                    wpN = pool_process<COUNT, OVF, GLASS>(K, K.wpool + (size_t)blockIdx.x * K.wpoolStride * RZ_GPOOL_FIELDS, K.wpoolStride, wpN, bstk, freeCount, redoCount);
+                if (!more) {
+                    if (GLASS && redoCount > 0) continue;   // the last passes' groups to render again
+                    break;
+                }
+                if (freeCount < need) break;   // (cannot be: see above -- but a claim must not run without its slots)
+            }
 #ifdef RZ_PROF
             ++wl_claims;
 #endif
-            render_claim_compact<COUNT, OVF, COMPACT>(K, M, ci, lds_raw, wpN, freeCount);
+            render_claim_compact<COUNT, OVF, COMPACT, GLASS>(K, M, ci, nRedo, redoCount, lds_raw, wpN, freeCount);
+            redoCount -= nRedo;
         }
     } else {
         for (;;) {
@@ -1159,7 +1350,10 @@ SamplesPlan plan_render_samples(int spp, int nSlots, bool glass) {
     // (measured: C2, 64 spp, 14.29 -> 13.28 ms; 128 spp C5 144.2 -> 143.0.  Several batches per pixel -- a claim is then a few
     //  pixels' batches: at mid-round the gain was gone at 256 spp, on the final code it is back: C3 47.3 -> 44.7 ms, one rank's
     //  share of a 4- / 8-GPU weak-scaling frame (256 / 512 spp) 11.88 -> 11.25 / 11.85 -> 11.70 ms)
-    p.compact = compact && !glass && p.perClaim > 0 && nBatches <= RZ_CLAIM_UNITS_LARGE;
+    // Transparent scenes compact too (round 4: glass_resolve_unit); RZ_GLASS_CLAIMS=0 keeps them on the speculating group code (A/B aid).
+    bool glassClaims = true;
+    if (const char* e = std::getenv("RZ_GLASS_CLAIMS")) glassClaims = std::atoi(e) != 0;
+    p.compact = compact && (!glass || glassClaims) && p.perClaim > 0 && nBatches <= RZ_CLAIM_UNITS_LARGE;
     if (spp < 64 && !p.compact) p.perClaim = 0;          // (the plain persistent loop never paid for several pixels per wave: C4 9.4 -> 10.8 ... 19.9 ms)
     p.claimUnits = 0;
     if (p.compact) {
@@ -1203,7 +1397,13 @@ void launch_render_samples(const KParams& K, bool counted, bool glass, hipStream
 #define RZ_LAUNCH_SAMPLES(C, G, O, M) hipLaunchKernelGGL((rz_render_samples<C, G, O, M>), g, b, lds, stream, K, nGroups, (unsigned)perClaim, (unsigned)plan.nClaims, (unsigned)plan.runShift)
     // (trace_spread for the third and later segments: launches of several pixels per wave over scenes of several instances)
     const bool spread = K.spreadTrace != 0 && K.spp < 64;
-    if (glass && spread) {
+    if (glass && compact && plan.claimUnits == RZ_CLAIM_UNITS_LARGE) {
+        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, true, true, RZ_CLAIM_UNITS_LARGE); else RZ_LAUNCH_SAMPLES(true, true, false, RZ_CLAIM_UNITS_LARGE); }
+        else { if (ovf) RZ_LAUNCH_SAMPLES(false, true, true, RZ_CLAIM_UNITS_LARGE); else RZ_LAUNCH_SAMPLES(false, true, false, RZ_CLAIM_UNITS_LARGE); }
+    } else if (glass && compact) {
+        if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, true, true, RZ_CLAIM_UNITS_SMALL); else RZ_LAUNCH_SAMPLES(true, true, false, RZ_CLAIM_UNITS_SMALL); }
+        else { if (ovf) RZ_LAUNCH_SAMPLES(false, true, true, RZ_CLAIM_UNITS_SMALL); else RZ_LAUNCH_SAMPLES(false, true, false, RZ_CLAIM_UNITS_SMALL); }
+    } else if (glass && spread) {
         if (counted) { if (ovf) RZ_LAUNCH_SAMPLES(true, true, true, 1); else RZ_LAUNCH_SAMPLES(true, true, false, 1); }
         else { if (ovf) RZ_LAUNCH_SAMPLES(false, true, true, 1); else RZ_LAUNCH_SAMPLES(false, true, false, 1); }
     } else if (glass) {

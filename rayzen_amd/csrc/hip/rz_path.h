@@ -263,12 +263,17 @@ __device__ __forceinline__ void snapshot_load(const KParams& K, Path& P, Tally& 
 }
 
 // FS:720-769: choose the next direction at the parked surface point and move on.
-// SNAP: keep the state in front of the sample's first transparent scatter (snapshot_store; only where K.snap is set).
-template <bool COUNT, bool GLASS, bool SNAP = false>
+// GMODE (transparent scenes): 1 -- keep the state in front of the sample's first transparent scatter (snapshot_store; only where
+// K.snap is set); 2 -- the path must not read currentIor at all (a pooled path of a compacting claim, whose pixel's earlier
+// samples may not be through yet): it stops in front of the transparent scatter, P.usedIor tells the caller, nothing is changed.
+template <bool COUNT, bool GLASS, int GMODE = 0>
 __device__ __forceinline__ void scatter(const KParams& K, Path& P, Tally& c) {
     RZ_T0();
-    if (COUNT) c.scatters += 1;
     const DevMaterial M = K.materials[P.hmat];
+    if constexpr (GLASS && GMODE == 2) {
+        if (M.transparency > 0.0f) { P.usedIor = 1; P.mode = MODE_DONE; return; }
+    }
+    if (COUNT) c.scatters += 1;
     const float fb2 = (float)(P.bounce * P.bounce), fb = (float)P.bounce;
     v2 tempseed;
     tempseed.x = (P.seed.x * fb2) * 12793.46f + fb * 1423.34f;
@@ -278,7 +283,7 @@ __device__ __forceinline__ void scatter(const KParams& K, Path& P, Tally& c) {
     const v3 hitNormal = P.hn;
     v3 dir = P.pdir;
     if (GLASS && M.transparency > 0.0f) {
-        if constexpr (SNAP) {
+        if constexpr (GMODE == 1) {
             if (K.snap != nullptr && !P.usedIor) snapshot_store<COUNT>(K, P, c);
         }
         P.usedIor = 1;
@@ -335,15 +340,15 @@ __device__ __forceinline__ void scatter(const KParams& K, Path& P, Tally& c) {
 }
 
 // Lighting of the parked point is complete (or there are no lights): FS:717, then scatter.
-template <bool COUNT, bool GLASS, bool SNAP = false>
+template <bool COUNT, bool GLASS, int GMODE = 0>
 __device__ __forceinline__ void finish_lighting(const KParams& K, Path& P, Tally& c) {
     P.addLight = P.throughput * P.lacc;
     P.color = P.color + P.addLight;
-    scatter<COUNT, GLASS, SNAP>(K, P, c);
+    scatter<COUNT, GLASS, GMODE>(K, P, c);
 }
 
 // Advance a path by the result of the closest-hit query of its current ray.
-template <bool COUNT, bool GLASS = true, bool SNAP = false>
+template <bool COUNT, bool GLASS = true, int GMODE = 0>
 __device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, const HitRec& h, Tally& c) {
     if (P.mode == MODE_SEGMENT) {
         if (!found) {   // FS:705-711
@@ -365,10 +370,10 @@ __device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, c
                          : mk3(0.05f * M.albedo[0], 0.05f * M.albedo[1], 0.05f * M.albedo[2]);
             P.li = 0;
             if (K.nLights > 0) { start_light<COUNT, GLASS>(K, P, c); return; }
-            finish_lighting<COUNT, GLASS, SNAP>(K, P, c);
+            finish_lighting<COUNT, GLASS, GMODE>(K, P, c);
             return;
         }
-        scatter<COUNT, GLASS, SNAP>(K, P, c);
+        scatter<COUNT, GLASS, GMODE>(K, P, c);
         return;
     }
     // MODE_SHADOW: the body of one iteration of FS:511-526
@@ -393,7 +398,7 @@ __device__ __forceinline__ void advance(const KParams& K, Path& P, bool found, c
     if (lit) { RZ_T0(); if (COUNT) c.lit_lights += 1; shade_light<GLASS>(K, P); RZ_T1(c, 6); }
     P.li += 1;
     if (P.li < K.nLights) { start_light<COUNT, GLASS>(K, P, c); return; }
-    finish_lighting<COUNT, GLASS, SNAP>(K, P, c);
+    finish_lighting<COUNT, GLASS, GMODE>(K, P, c);
 }
 
 }  // namespace rz

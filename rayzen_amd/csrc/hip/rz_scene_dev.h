@@ -130,16 +130,17 @@ struct KParams {
     unsigned* wpool;        // [resident wave][RZ_GPOOL_FIELDS][wpoolStride]
     uint32_t wpoolStride;   // slots per field: wpoolChunk + the most one claim can park
     uint32_t wpoolChunk;    // the wave traces its pool when it holds at least this many paths (and at the end of the launch)
-    int32_t* wmeta;         // [resident wave][2 nWaitSlots]: the group in each of the wave's wait slots | its outstanding paths (-1: the slot is free)
-    uint32_t slotFloats;    // floats per wait slot: batches per pixel x 384
+    int32_t* wmeta;         // [resident wave][4 nWaitSlots]: the group in each of the wave's wait slots | its outstanding paths (-1: the slot is free) | transparent scenes: 1 = one of its pooled paths met glass | ... the groups to render again (rz_kernels.hip: redo list)
+    uint32_t slotFloats;    // floats per group in a wait slot and in the claim scratch: batches per pixel x 384 (+ 64 in transparent scenes: the currentIor each pixel ends with)
     int32_t nWaitSlots;     // wait slots per resident wave (<= 64, >= twice the groups of a claim)
     int32_t claimUnits;     // units of a claim (8 or 16: the kernel's COMPACT parameter)
+    uint32_t claimScratchFloats;    // floats of a resident wave's claim scratch (groups of a claim x slotFloats); its wait slots follow
     int32_t drainEachClaim; // 1: a wave traces its pool to the end after every claim (RZ_CROSS_CLAIM_POOL=0: the per-claim pools of round 2; a scheduling choice, same image)
     int32_t regularBoxes;   // 1: every BLAS child box has min <= max on every axis (no NaN): the octant-specialised slab test may be used
     // ---- transparent scenes, persistent launches: per resident wave, the state of each lane's sample in front of its first
     //      transparent scatter (rz_path.h: snapshot_store), from which the sample's second version starts; null: re-runs start at the camera
     float* snap;            // [resident wave][snapStride] floats
-    uint32_t snapStride;    // >= (RZ_SNAP_FIELDS + RZ_SNAP_TALLY) * 64
+    uint32_t snapStride;    // >= (RZ_SNAP_FIELDS + RZ_SNAP_TALLY + RZ_GVER_ROWS) * 64
 };
 
 // Arguments of the device TLAS rebuild (rz_tlas_device.hip: rz_tlas_refit; filled in by rz_context.hip).
@@ -168,5 +169,6 @@ constexpr int RZ_CLAIM_UNITS_SMALL = 8, RZ_CLAIM_UNITS_LARGE = 16;
 constexpr int RZ_POOL_FIELDS = 23;      // the parked path (13), its query (8), the items of a B phase (2): rz_trace.h, namespace poolf
 constexpr int RZ_GPOOL_FIELDS = RZ_POOL_FIELDS + 1;     // a wave's pool: ... + the wait slot of the group a parked path belongs to (field 23)
 constexpr int RZ_SNAP_FIELDS = 19, RZ_SNAP_TALLY = 14;  // rz_path.h: snapshot_store -- a sample's state in front of its first transparent scatter (+ its tallies, counting launches)
+constexpr int RZ_GVER_ROWS = 12;        // rz_kernels.hip: glass_resolve_unit -- the two versions of a sample's addends, [version][6] rows of 64 floats behind the snapshot rows
 
 }  // namespace rz
