@@ -727,6 +727,8 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
             K.wslotStride = (uint32_t)(claimScratchFloats + nSlots * slotFloats + slotPad);
             K.claimUnits = plan.claimUnits;
             K.claimScratchFloats = (uint32_t)claimScratchFloats;
+            K.glassBoxHint = 1;
+            if (const char* e = std::getenv("RZ_GLASS_BOX_HINT")) K.glassBoxHint = std::atoi(e) != 0 ? 1 : 0;      // A/B and test aid
             K.slotFloats = (uint32_t)slotFloats;
             K.nWaitSlots = nSlots;
             K.wmeta = static_cast<int32_t*>(c->dDeferFlags.p);
@@ -1248,6 +1250,9 @@ int rz_render_counted(rz_ctx* c, rz_counters* out) {
 }
 
 int rz_sync(rz_ctx* c) {
+#ifdef RZ_GSTATS
+    if (c) { (void)hipStreamSynchronize(c->stream); dump_gstats(); }
+#endif
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
     return guarded(c, "rz_sync", [&]() -> int {
         RZ_HIP(c, hipStreamSynchronize(c->stream));

@@ -20,6 +20,9 @@ int compute_hemi0(float out[3], hipStream_t stream);
 #ifdef RZ_PROF
 void dump_wave_log(int nWaves);
 #endif
+#ifdef RZ_GSTATS
+void dump_gstats();
+#endif
 
 // ---- rz_tlas_device.hip
 void launch_tlas_refit(const TlasWork& W, hipStream_t s);

@@ -33,6 +33,12 @@ constexpr int WAVES_PER_BLOCK = RZ_WAVES_PER_BLOCK;
 #ifdef RZ_PROF
 __device__ unsigned long long rz_wave_log[1 << 17][3];     // diagnostic build: start, end (100 MHz ticks), hw id
 #endif
+#ifdef RZ_GSTATS
+__device__ unsigned long long rz_gstats[8];                // diagnostic build (transparent scenes on claims): [0] units [1] units resolved in the wave [2] groups rendered again [3] re-run rounds [4] paths parked [5] pooled paths that met glass
+#define RZ_GSTAT(i, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&rz_gstats[i], (unsigned long long)(n)); } while (0)
+#else
+#define RZ_GSTAT(i, n) do { } while (0)
+#endif
 
 template <bool COUNT>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64, RZ_MIN_WAVES_PER_SIMD) void rz_render_pixels(const KParams K) {
@@ -693,7 +699,7 @@ __device__ __forceinline__ void slot_sums(const KParams& K, const float* __restr
 #define RZ_GLASS_BOX_MAX_DFS 64
 #endif
 __device__ __forceinline__ bool may_hit_glass(const KParams& K, const bool cand, const v3 o, const v3 d) {
-    if (K.nTlasDfs > RZ_GLASS_BOX_MAX_DFS || rz_ballot(cand) == 0ull) return false;
+    if (K.glassBoxHint == 0 || K.nTlasDfs > RZ_GLASS_BOX_MAX_DFS || rz_ballot(cand) == 0ull) return false;
     const v3 inv = rcp3(d);
     bool hit = false;
     for (int pos = 0; pos < K.nTlasDfs; ++pos) {
@@ -708,7 +714,7 @@ __device__ __forceinline__ bool may_hit_glass(const KParams& K, const bool cand,
 
 template <bool COUNT, bool OVF>
 __device__ __forceinline__ void glass_resolve_unit(const KParams& K, const BlasStackT<OVF>& bstk, Path& P, const bool mine, const int samp, const int lanePix,
-                                                   const float iorStart, float& iorEnd, Tally& c, const Tally& cStart) {
+                                                   const float iorStart, float& iorEnd, Tally& c) {
     const int lane = threadIdx.x & 63;
     float* const V = K.snap + (size_t)blockIdx.x * K.snapStride + (size_t)(RZ_SNAP_FIELDS + RZ_SNAP_TALLY) * 64 + lane;      // [version][6] rows, this lane's column
     unsigned key0 = __float_as_uint(iorStart), key1 = 0u, out0 = 0u, out1 = 0u;     // per version: the currentIor it was run from / left behind (bit patterns: a NaN must equal itself)
@@ -717,17 +723,7 @@ __device__ __forceinline__ void glass_resolve_unit(const KParams& K, const BlasS
     unsigned want = __float_as_uint(iorStart);
     bool running = mine;                // lanes whose version is being computed in this round
     Tally tv0 = {}, tv1 = {};           // (counting launches: the tallies of each version's whole run)
-    Tally att = c;                      // ... of the run in progress: round 0 continues the run the claim has begun
-    if (COUNT) {
-        // what this lane's sample has tallied so far in this unit = c - cStart
-        att = {};
-        att.samples = c.samples - cStart.samples; att.traversals = c.traversals - cStart.traversals; att.tlas_nodes = c.tlas_nodes - cStart.tlas_nodes;
-        att.tlas_leaf_indices = c.tlas_leaf_indices - cStart.tlas_leaf_indices; att.instances = c.instances - cStart.instances;
-        att.blas_nodes = c.blas_nodes - cStart.blas_nodes; att.triangles = c.triangles - cStart.triangles; att.materials = c.materials - cStart.materials;
-        att.light_fetches = c.light_fetches - cStart.light_fetches; att.scatters = c.scatters - cStart.scatters;
-        att.diffuse_scatters = c.diffuse_scatters - cStart.diffuse_scatters; att.hemi_draws = c.hemi_draws - cStart.hemi_draws;
-        att.lit_lights = c.lit_lights - cStart.lit_lights; att.triangles_past_u = c.triangles_past_u - cStart.triangles_past_u;
-    }
+    Tally att = c;                      // ... of the run in progress: round 0 continues the run the claim has begun (c: this unit's tallies so far)
     iorEnd = iorStart;
     // (every round gives each pixel's first blocked sample the version it lacks: at most 64 rounds per unit; the bound is a backstop)
     for (int round = 0; round < 130; ++round) {
@@ -782,6 +778,7 @@ __device__ __forceinline__ void glass_resolve_unit(const KParams& K, const BlasS
         if (need == 0ull) break;
         // ---- the lanes that lack a version start it from their snapshots
         running = ((need >> lane) & 1ull) != 0ull;
+        RZ_GSTAT(3, 1);
         if (running) {
             P.color = mk3(0.0f, 0.0f, 0.0f);
             if (COUNT) att = {};
@@ -797,8 +794,8 @@ __device__ __forceinline__ void glass_resolve_unit(const KParams& K, const BlasS
         P.addLight = mk3(R[0], R[64], R[128]);
         P.addSky = mk3(R[192], R[256], R[320]);
     }
-    if (COUNT) {
-        c = cStart;
+    if (COUNT) {        // the unit's tallies are those of the versions its chains chose
+        c = {};
         if (mine) tally_add(c, chosen ? tv1 : tv0);
     }
     P.mode = MODE_DONE;
@@ -861,8 +858,8 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
         const int g = nBatches == 1 ? unit : unit / nBatches, b = unit - g * nBatches;
         bool mine = false;
         float iorStart = 1.0f;
-        Tally cStart = {};
-        if (COUNT && GLASS) cStart = c;
+        Tally cu = {};                                  // counting launches of transparent scenes: this unit's own tallies (a snapshot keeps
+        Tally& tu = (COUNT && GLASS) ? cu : c;          // its sample's prefix, a resolved unit counts its chosen versions alone)
         {
             const int slot = group_of(g) * ppw + pixInUnit;
             const int localTile = slot >> 6, l = slot & 63;
@@ -896,7 +893,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
                 P.fragSum = fragx + fragy;
                 P.color = mk3(0.0f, 0.0f, 0.0f);
                 P.samp = K.sampleBase + s;
-                begin_sample<COUNT>(K, P, c);
+                begin_sample<COUNT>(K, P, tu);
                 if constexpr (GLASS) P.ior = iorStart;
             }
         }
@@ -915,11 +912,11 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
                 RZ_SITE(c, 6);
                 const unsigned long long tq0_ = __builtin_amdgcn_s_memtime();
 #endif
-                const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, c);
+                const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, tu);
 #ifdef RZ_PROF
                 c.rt[c.rnd & 7] += __builtin_amdgcn_s_memtime() - tq0_;
 #endif
-                advance<COUNT, GLASS, GLASS ? 1 : 0>(K, P, found, h, c);
+                advance<COUNT, GLASS, GLASS ? 1 : 0>(K, P, found, h, tu);
             }
 #ifdef RZ_PROF
             if (c.rnd < 7) ++c.rnd;
@@ -933,8 +930,11 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
             // did a sample of this unit read currentIor?  Then (and in counting launches, whose tallies must be those of the final
             // versions alone, and when a group is rendered again) the unit is resolved here; otherwise it was clean.
             float iorEnd = iorStart;
+            RZ_GSTAT(0, 1);
+            if (COUNT || redo || rz_ballot(P.usedIor != 0) != 0ull) RZ_GSTAT(1, 1);
             if (COUNT || redo || rz_ballot(P.usedIor != 0) != 0ull)
-                glass_resolve_unit<COUNT, OVF>(K, bstk, P, mine, K.sampleBase + b * 64 + sampInUnit, pixInUnit, iorStart, iorEnd, c, cStart);
+                glass_resolve_unit<COUNT, OVF>(K, bstk, P, mine, K.sampleBase + b * 64 + sampInUnit, pixInUnit, iorStart, iorEnd, tu);
+            if (COUNT) tally_add(c, cu);
             iorCarry = iorEnd;
             if (b == nBatches - 1) addBase[(size_t)g * GF + (size_t)nBatches * 384 + lane] = iorEnd;       // (read at this lane's pixel's first lane by the sums)
         }
@@ -957,6 +957,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
             W[BACK * WS + sl] = ((unsigned)P.bounce << 16) | ((unsigned)unit << 6) | (unsigned)lane;     // (the unit becomes the batch within its group at the end of the claim)
         }
         nPool += mask_count(pm);
+        if (GLASS) RZ_GSTAT(4, mask_count(pm));
 #ifdef RZ_PROF
         c.t[4] += __builtin_amdgcn_s_memtime() - tph0_;
 #endif
@@ -1118,6 +1119,9 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
             const unsigned bl = back & 63u;
             A[192 + bl] = P.addSky.x; A[256 + bl] = P.addSky.y; A[320 + bl] = P.addSky.z;
             if (GLASS && P.usedIor) meta[2 * NS + wslot] = 1;       // it stopped in front of a transparent scatter: its group is rendered again
+#ifdef RZ_GSTATS
+            if (GLASS && P.usedIor) atomicAdd(&rz_gstats[5], 1ull);
+#endif
             atomicAdd(meta + NS + wslot, -1);      // (nothing comes back: the wave looks at the counts once, after the shade rounds)
         }
         const unsigned long long pm = rz_ballot(parked);
@@ -1152,6 +1156,7 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
             meta[NS + lane] = -1;
         }
         redoCount += mask_count(dirty);
+        RZ_GSTAT(2, mask_count(dirty));
         freeCount += mask_count(dirty);
         ready &= ~dirty;
     }
@@ -1268,6 +1273,15 @@ void launch_render_pixels(const KParams& K, bool counted, hipStream_t stream) {
         hipLaunchKernelGGL(rz_render_pixels<false>, dim3(blocks), dim3(WAVES_PER_BLOCK * 64), lds, stream, K);
 }
 
+#ifdef RZ_GSTATS
+void dump_gstats() {
+    unsigned long long h[8] = {};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(rz_gstats), sizeof h) != hipSuccess) return;
+    fprintf(stderr, "[rz_gstats] units %llu  resolved in the wave %llu  groups rendered again %llu  re-run rounds %llu  paths parked %llu  pooled paths that met glass %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+    unsigned long long z[8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(rz_gstats), z, sizeof z);
+}
+#endif
 #ifdef RZ_PROF
 void dump_wave_log(int nWaves) {
     static std::vector<unsigned long long> h;

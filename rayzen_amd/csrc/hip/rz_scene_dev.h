@@ -134,6 +134,7 @@ struct KParams {
     uint32_t slotFloats;    // floats per group in a wait slot and in the claim scratch: batches per pixel x 384 (+ 64 in transparent scenes: the currentIor each pixel ends with)
     int32_t nWaitSlots;     // wait slots per resident wave (<= 64, >= twice the groups of a claim)
     int32_t claimUnits;     // units of a claim (8 or 16: the kernel's COMPACT parameter)
+    int32_t glassBoxHint;   // transparent scenes: 1 = a late path whose ray passes the box of an instance with glass in it is not parked (rz_kernels.hip: may_hit_glass; RZ_GLASS_BOX_HINT=0 switches it off: same image)
     uint32_t claimScratchFloats;    // floats of a resident wave's claim scratch (groups of a claim x slotFloats); its wait slots follow
     int32_t drainEachClaim; // 1: a wave traces its pool to the end after every claim (RZ_CROSS_CLAIM_POOL=0: the per-claim pools of round 2; a scheduling choice, same image)
     int32_t regularBoxes;   // 1: every BLAS child box has min <= max on every axis (no NaN): the octant-specialised slab test may be used

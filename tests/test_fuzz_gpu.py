@@ -148,3 +148,72 @@ def test_a_launch_that_gets_no_memory_for_its_cross_claim_pools_renders_the_same
     ref = oracle_render(sc, W, H, spp, b, nthreads=16)
     for f in frames:
         assert (f.view(np.uint32) == ref.view(np.uint32)).all(), f"seed {seed}: " + mismatch_report(f, ref)
+
+
+# ---- transparent scenes on the compacting claims (round 4: glass_resolve_unit, the redo list, may_hit_glass) ------------------
+
+N_GLASS_CLAIMS = int(os.environ.get("RZ_FUZZ_GLASS_CLAIM_SEEDS", "96"))
+
+
+def _transparent_scene(seed):
+    """A random scene in which at least one instanced mesh uses a transparent material (so that the launch is a transparent one)."""
+    for k in range(50):
+        sc, rng = random_scene(seed + 100000 * k)
+        tri = sc.arrays[S.BIND_TRIANGLES]
+        if (sc.materials["transparency"][tri["materialIndex"]] > 0).any():
+            return sc, rng
+    raise AssertionError("no transparent scene found")
+
+
+@pytest.mark.parametrize("seed", range(N_GLASS_CLAIMS))
+def test_random_transparent_scene_through_claims(seed, monkeypatch):
+    """FS:674's currentIor on the compacting claims, forced onto frames small enough for the oracle: random scenes with several
+    transparent materials of different ior (so that a sample can need more than two versions), mirrors and diffuse surfaces,
+    1 ... 130 spp (several pixels per wave, also when the spp does not divide 64; several batches per pixel, currentIor carried
+    from batch to batch), claims of 2 ... 16 groups, stratified or in runs, pools traced in the middle of a launch and at its
+    end, few wait slots (claims that must wait for the pool), frames continued with sample_base > 0 (currentIor carried from
+    launch to launch).  Units in which a sample reads currentIor are resolved in the wave from snapshots; pooled paths that
+    meet glass send their group to the redo list.  Every pixel against the oracle, bit for bit.
+    Reference semantics: fragment_shader.glsl:674, 723-746."""
+    sc, rng = _transparent_scene(9000 + seed)
+    W, H = int(rng.integers(40, 161)), int(rng.integers(24, 97))
+    spp, b = int(rng.choice([1, 2, 3, 8, 16, 17, 40, 64, 100, 130])), int(rng.integers(2, 9))
+    sc.camera.aspect = W / H
+    sc.camera.update()
+    per_claim = int(rng.choice([2, 4, 8, 16]))
+    monkeypatch.setenv("RZ_GROUPS_PER_CLAIM", str(per_claim))
+    monkeypatch.setenv("RZ_CLAIM_RUN", str(int(rng.choice([1, 2, per_claim]))))
+    monkeypatch.setenv("RZ_WPOOL_CHUNK", str(int(rng.choice([24, 64, 200]))))
+    if rng.random() < 0.3:
+        monkeypatch.setenv("RZ_WAIT_SLOTS", "1")          # (raised to twice the groups of a claim: the fewest a launch may have)
+    if rng.random() < 0.25:
+        monkeypatch.setenv("RZ_GLASS_BOX_HINT", "0")      # every late path is parked: many groups are rendered again
+    chunk = int(rng.choice([0, 0, max(1, spp // 3)]))     # a third of the frames in several launches of `chunk` samples
+    from rayzen_amd.renderer import Renderer
+    r = Renderer(0)
+    gpu = hip_render(sc, W, H, spp, b, renderer=r, chunk=chunk or None)
+    plan = r.debug_last_plan()
+    name = r.last_kernel_name()
+    r.close()
+    assert plan["per_claim"] > 0 and plan["claim_units"] in (8, 16) and plan["transparent"] == 1, plan
+    assert name == "rz_render_samples<glass>+pool", name
+    ref = oracle_render(sc, W, H, spp, b, nthreads=16)
+    assert (gpu.view(np.uint32) == ref.view(np.uint32)).all(), f"seed {seed} ({W}x{H}, {spp} spp, {b} bounces, claims of {per_claim}, chunk {chunk}): " + mismatch_report(gpu, ref)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_transparent_claims_tallies_and_the_group_code(seed, monkeypatch):
+    """The counting launch of a transparent scene on claims (every unit resolved in the wave, the tallies those of the chosen
+    versions) against the oracle's tallies, and the image of the claims against the speculating group code (RZ_GLASS_CLAIMS=0)."""
+    sc, rng = _transparent_scene(9500 + seed)
+    W, H, spp, b = 96, 64, int(rng.choice([4, 16, 64, 100])), 5
+    sc.camera.aspect = W / H
+    sc.camera.update()
+    monkeypatch.setenv("RZ_GROUPS_PER_CLAIM", "4")
+    img, cnt = hip_render(sc, W, H, spp, b, counted=True)
+    ref, rc = oracle_render(sc, W, H, spp, b, nthreads=16, want_counters=True)
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all(), mismatch_report(img, ref)
+    assert cnt == rc
+    monkeypatch.setenv("RZ_GLASS_CLAIMS", "0")
+    grp = hip_render(sc, W, H, spp, b)
+    assert (grp.view(np.uint32) == ref.view(np.uint32)).all(), mismatch_report(grp, ref)
