@@ -284,10 +284,17 @@ def main(argv=None):
     kms = max(member_ms)
     reduce_ms = group.last_reduce_ms() if group is not None else None
 
+    rank_ms = None
     if mode == "ranks":
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if use_nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own kernel time and its share of the reduce (HIP events on its render stream), gathered so that ONE line
+        # splits a step into kernel and collective: [kernel ms, reduce ms or -1] per rank
+        mine = torch.tensor([kms, (reduce_ms[1] if reduce_ms is not None else -1.0)], dtype=torch.float64, device=dev if use_nccl else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_ms = [[float(x[0]), float(x[1])] for x in allr]
 
     total_samples = W * H * spp_total * a.steps
     value = total_samples / elapsed / 1e6
@@ -319,6 +326,14 @@ def main(argv=None):
             out["reduce_ms"] = round(reduce_ms[0] if reduce_ms[0] >= 0 else reduce_ms[1], 3)
             out["reduce_ms_note"] = "HIP events around rz_group_reduce on the root member's stream (last timed step)"
         out["kernel_ms_per_member"] = [round(x, 3) for x in member_ms]
+        if rank_ms is not None:
+            out["kernel_ms_per_rank"] = [round(k, 3) for k, _ in rank_ms]
+            out["reduce_ms_per_rank"] = [round(r_, 3) for _, r_ in rank_ms]
+        # how one step divides: the slowest rank's kernel, then the reduce behind it; what is left is launch and fence overhead
+        slow_k = max([k for k, _ in rank_ms]) if rank_ms is not None else kms
+        red = out.get("reduce_ms")
+        out["step_split_ms"] = {"slowest_kernel": round(slow_k, 3), "reduce": red, "step": out["ms_per_step"],
+                                "other": round(out["ms_per_step"] - slow_k - (red or 0.0), 3)}
     if rank == 0:
         if group is not None:
             final = group.read_frame()

@@ -26,8 +26,12 @@ HOST_SO = os.path.join(LIB, "librayzen_host.so")
 # -fno-slp-vectorize: left on, the SLP vectoriser pairs neighbouring f32 adds/multiplies into v_pk_*_f32 on 64-bit
 # register tuples; in the render kernel that cost 25 VGPRs (167 vs 142) for no gain in issue slots.  Where packed math
 # does pay (the two-plane slab test) it is written explicitly (rz_trace.h).
+# -mllvm -greedy-regclass-priority-trumps-globalness (round 4): of sixteen register-allocator / scheduler switches tried on the
+# render kernels (profiles/r04_regs/) the only one that moved anything the right way: 39 -> 34 spilled VGPRs in the C2 kernel,
+# C2 10.88 -> 10.79 ms, C4 neutral.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-               "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+               "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-greedy-regclass-priority-trumps-globalness",
+               "-Wall", "-Wno-unused-function"]
 CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra"]
 
 

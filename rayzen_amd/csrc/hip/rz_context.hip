@@ -823,9 +823,9 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     if (perWave * 4 > 160 * 1024)   // sized for the largest (4-wave) workgroup
         return fail(c, RZ_ERR_BAD_SCENE, "BLAS depth %d needs %zu B of LDS stack per wave; the limit is %d", c->maxBlasDepth, perWave, 40 * 1024);
     if (counted) {
-        rc = ensure(c, c->dCounters, sizeof(DevCounters) + 128 * sizeof(unsigned long long));
+        rc = ensure(c, c->dCounters, sizeof(DevCounters) + 160 * sizeof(unsigned long long));
         if (rc != RZ_OK) return rc;
-        RZ_HIP(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(DevCounters) + 128 * sizeof(unsigned long long), c->stream));
+        RZ_HIP(c, hipMemsetAsync(c->dCounters.p, 0, sizeof(DevCounters) + 160 * sizeof(unsigned long long), c->stream));
         K.counters = static_cast<DevCounters*>(c->dCounters.p);
     }
     // The event pair brackets the render kernels of this call (for the one-lane-per-sample path: the
@@ -858,7 +858,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
         out->pixels = h.pixels;
         out->scatters = h.scatters; out->diffuse_scatters = h.diffuse_scatters; out->hemi_draws = h.hemi_draws; out->lit_lights = h.lit_lights; out->triangles_past_u = h.triangles_past_u;
 #ifdef RZ_PROF
-        unsigned long long pr[128];
+        unsigned long long pr[160];
         RZ_HIP(c, hipMemcpy(pr, static_cast<char*>(c->dCounters.p) + sizeof(DevCounters), sizeof pr, hipMemcpyDeviceToHost));
         for (int r = 0; r < 8; ++r) {       // per query round of a path: 0 primary, 1-2 shadow, 3 first bounce, ...
             const unsigned long long* q = pr + 32 + 11 * r;
@@ -875,6 +875,7 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
         fprintf(stderr, "[rz_prof] compacting claims: phase 1 (units) %llu  pool rounds %llu wave cycles; %llu rounds with %llu paths = %.1f lanes per round\n", pr[23], pr[28], pr[29], pr[30], pr[29] ? (double)pr[30] / (double)pr[29] : 0.0);
         fprintf(stderr, "[rz_prof] cross-claim pools: %llu traced, %llu queries in them, shade rounds %llu wave cycles\n", pr[29], pr[30], pr[28]);
         fprintf(stderr, "[rz_prof] pool_trace (a claim's pooled queries traced together): %llu wave cycles = T phases %llu + B phases %llu (of which refills %llu); round 7 above = its steps\n", pr[120], pr[121], pr[122], pr[123]);
+        fprintf(stderr, "[rz_prof] descend steps of the general (per-lane) walk by children entered: none %llu  one %llu  both %llu (lane-level; the scalar-unit steps are not in here); in the pools' walks: none %llu  one %llu  both %llu\n", pr[132], pr[133], pr[134], pr[136], pr[137], pr[138]);
         fprintf(stderr, "[rz_prof] wait slots: end-of-claim sections %llu wave cycles (of which the claim-end sums %llu); slot_sums inside pool_process %llu\n", pr[124], pr[126], pr[125]);
         fprintf(stderr, "[rz_prof] inside advance: sky %llu  hit %llu  start_light %llu  shade_light %llu  scatter %llu (hemisphere %llu)  shadow step %llu\n", pr[22], pr[23], pr[24], pr[25], pr[26], pr[27], pr[28]);
 #endif

@@ -180,6 +180,11 @@ __device__ __forceinline__ int slot_y(int l, bool morton) { return morton ? (((l
 #ifdef RZ_PROF
 // per-query-round site counters and trace cycles -> pr[32 + 11 r + k] (k < 10: rp, k == 10: rt of lane 0)
 __device__ __forceinline__ void rz_prof_rounds(const Tally& c, unsigned long long* pr) {
+    for (int k = 0; k < 8; ++k) {       // descend steps by how many children they enter -> pr[132 + k]
+        unsigned x = c.ps[k];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&pr[132 + k], (unsigned long long)x);
+    }
     for (int r = 0; r < 8; ++r) {
         for (int k = 0; k < 10; ++k) {
             unsigned x = c.rp[r][k];
@@ -197,6 +202,7 @@ __device__ __forceinline__ void tally_add(Tally& a, const Tally& b) {
     a.triangles_past_u += b.triangles_past_u; a.scatters += b.scatters; a.diffuse_scatters += b.diffuse_scatters; a.hemi_draws += b.hemi_draws; a.lit_lights += b.lit_lights;
 #ifdef RZ_PROF
     for (int k = 0; k < 16; ++k) a.p[k] += b.p[k];
+    for (int k = 0; k < 8; ++k) a.ps[k] += b.ps[k];
     for (int k = 0; k < 20; ++k) a.t[k] += b.t[k];
     for (int r = 0; r < 8; ++r) { a.rt[r] += b.rt[r]; for (int k = 0; k < 10; ++k) a.rp[r][k] += b.rp[r][k]; }
 #endif

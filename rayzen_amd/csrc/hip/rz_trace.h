@@ -45,6 +45,7 @@ struct Tally {          // per-thread counts of the REFERENCE algorithm's memory
     unsigned scatters, diffuse_scatters, hemi_draws, lit_lights;    // FS:720-761 executed | of them FS:755 | of those with a non-zero seed (binary64 acos / sin / cos evaluated) | FS:636-659 / 589-607 evaluated
 #ifdef RZ_PROF          // diagnostic build only: where do the lanes of a wave spend their iterations?
     unsigned p[16];
+    unsigned ps[8];             // descend steps by lane: [0] both child boxes missed or culled, [1] one entered, [2] both (one stacked); [4..6] the same for the pool's walks (pool_trace)
     int rnd;                    // which closest-hit query of its path this lane is in (0 primary, 1-2 shadow, 3.. bounces), capped at 7
     unsigned rp[8][10];         // per query round: wave-execs / lanes of [0,1] descend steps [2,3] triangle tests [4,5] instance entries [6,7] uniform-pair steps [8,9] queries
     unsigned long long rt[8];   // per query round: wave cycles inside trace_closest (lane 0's clock)
@@ -342,6 +343,9 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
                 //  were lane masks merged by six scalar instructions per step)
                 auto step = [&](bool hl, float tl, bool hr, float tr, int lenc, int renc) {
                     const bool takeR = hr && !(tr > tLoc);
+#ifdef RZ_PROF
+                    { const bool takeL_ = hl && !(tl > tLoc); c.ps[(takeR ? 1 : 0) + (takeL_ ? 1 : 0)] += 1u; }
+#endif
                     if (hl && takeR) push_entry(bstk, sp, make_uint2((unsigned)lenc, __float_as_uint(tl)));
                     int next = takeR ? renc : ((tl > tLoc) ? -1 : lenc);
                     if (!hl && !takeR) {
@@ -918,6 +922,9 @@ __device__ __forceinline__ void pool_trace(const KParams& K, unsigned* __restric
                     RZ_SLAB_PAIR(-1, RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
                     const int lenc = __float_as_int(p3.x), renc = __float_as_int(p3.y);
                     const bool takeR = hr && !(tr > tLoc);
+#ifdef RZ_PROF
+                    { const bool takeL_ = hl && !(tl > tLoc); c.ps[4 + (takeR ? 1 : 0) + (takeL_ ? 1 : 0)] += 1u; }
+#endif
                     if (hl && takeR) push_entry(bstk, sp, make_uint2((unsigned)lenc, __float_as_uint(tl)));
                     int nxt = takeR ? renc : ((tl > tLoc) ? -1 : lenc);
                     if (!hl && !takeR) {
