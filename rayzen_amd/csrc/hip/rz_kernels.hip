@@ -693,8 +693,10 @@ __device__ __forceinline__ void slot_sums(const KParams& K, const float* __restr
 // speculatively, every later sample that lacks that value -- until every chain walks through.  Exactly the additions the
 // sequential shader makes, from exactly the currentIor it would have handed each sample.
 // The chain is walked on the SCALAR unit over the lanes that read currentIor (v_readlane of their keys and results): the
-// versions' bookkeeping is four registers per lane, their addends wait in the wave's scratch (K.snap, behind the snapshots) --
-// no LDS, so the whole BLAS stack stays there, unlike the group code's 5.4 KB of versions.
+// versions' bookkeeping is a few registers per lane, their addends wait in the wave's scratch (K.snap, behind the snapshots) --
+// no LDS, so the whole BLAS stack stays there, unlike the group code's 5.4 KB of versions.  The rounds of a resolved unit go
+// through the SAME trace / advance loop as the unit's first run (render_claim_compact): a second inlined copy of the walk
+// made the kernel 150 KB and its instruction-cache misses eight times the group code's (profiles/r04_glass/).
 // Which paths NOT to park in a transparent scene: a parked path that comes to a transparent scatter later costs its whole
 // group a second rendering (pool_process).  A ray can only reach glass through the world box of an instance that holds
 // transparent triangles (DevInstance.flags bit 1, a hint set at upload): the leaves of the pop-order TLAS list carry those
@@ -716,95 +718,6 @@ __device__ __forceinline__ bool may_hit_glass(const KParams& K, const bool cand,
         hit = hit || slab(o, inv, q[0], q[1], q[2], q[4], q[5], q[6], tmin);
     }
     return cand && hit;
-}
-
-template <bool COUNT, bool OVF>
-__device__ __forceinline__ void glass_resolve_unit(const KParams& K, const BlasStackT<OVF>& bstk, Path& P, const bool mine, const int samp, const int lanePix,
-                                                   const float iorStart, float& iorEnd, Tally& c) {
-    const int lane = threadIdx.x & 63;
-    float* const V = K.snap + (size_t)blockIdx.x * K.snapStride + (size_t)(RZ_SNAP_FIELDS + RZ_SNAP_TALLY) * 64 + lane;      // [version][6] rows, this lane's column
-    unsigned key0 = __float_as_uint(iorStart), key1 = 0u, out0 = 0u, out1 = 0u;     // per version: the currentIor it was run from / left behind (bit patterns: a NaN must equal itself)
-    int info0 = 0, info1 = 0;                                                       // bit 0: valid, bit 1: the sample read currentIor
-    int nextSlot = 0, chosen = 0;
-    unsigned want = __float_as_uint(iorStart);
-    bool running = mine;                // lanes whose version is being computed in this round
-    Tally tv0 = {}, tv1 = {};           // (counting launches: the tallies of each version's whole run)
-    Tally att = c;                      // ... of the run in progress: round 0 continues the run the claim has begun (c: this unit's tallies so far)
-    iorEnd = iorStart;
-    // (every round gives each pixel's first blocked sample the version it lacks: at most 64 rounds per unit; the bound is a backstop)
-    for (int round = 0; round < 130; ++round) {
-        // ---- run the lanes of this round to their ends (round 0: the paths the claim has begun; later: second versions from snapshots)
-        bool anyRun = rz_ballot(P.mode != MODE_DONE) != 0ull;
-        while (anyRun) {
-            if (P.mode != MODE_DONE) {
-                HitRec h;
-                const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, COUNT ? att : c);
-                advance<COUNT, true, 1>(K, P, found, h, COUNT ? att : c);
-            }
-            anyRun = rz_ballot(P.mode != MODE_DONE) != 0ull;
-        }
-        if (running) {
-            const unsigned o = __float_as_uint(P.ior);
-            const int inf = 1 | (P.usedIor ? 2 : 0);
-            float* const R = V + (size_t)nextSlot * 6 * 64;
-            R[0] = P.addLight.x; R[64] = P.addLight.y; R[128] = P.addLight.z;
-            R[192] = P.addSky.x; R[256] = P.addSky.y; R[320] = P.addSky.z;
-            if (nextSlot == 0) { key0 = want; out0 = o; info0 = inf; if (COUNT) tv0 = att; }
-            else { key1 = want; out1 = o; info1 = inf; if (COUNT) tv1 = att; }
-            nextSlot ^= 1;
-        }
-        // ---- walk the chains: the lanes that read currentIor, in sample order, on the scalar unit
-        const unsigned long long touch = rz_ballot(mine && (((info0 | info1) & 2) != 0));
-        unsigned long long need = 0ull;
-        int curPix = -1;
-        unsigned cur = 0u;
-        bool blocked = false;
-        iorEnd = iorStart;
-        chosen = 0;
-        for (unsigned long long rest = touch; rest != 0ull; rest &= rest - 1ull) {
-            const int k = (int)__builtin_ctzll(rest);
-            const int pix = __builtin_amdgcn_readlane(lanePix, k);
-            if (pix != curPix) { curPix = pix; cur = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(iorStart), k); blocked = false; }
-            const int i0 = __builtin_amdgcn_readlane(info0, k), i1 = __builtin_amdgcn_readlane(info1, k);
-            const unsigned k0 = (unsigned)__builtin_amdgcn_readlane((int)key0, k), k1 = (unsigned)__builtin_amdgcn_readlane((int)key1, k);
-            const bool has0 = (i0 & 1) && k0 == cur, has1 = (i1 & 1) && k1 == cur;
-            if (!has0 && !has1) {
-                // this sample was not run from the value its chain arrives with: it is run again; the samples behind it are walked
-                // on the guess that it leaves the value alone
-                need |= 1ull << k;
-                if (lane == k) want = cur;
-                blocked = true;
-                continue;
-            }
-            const int v = has0 ? 0 : 1;
-            if (!blocked && lane == k) chosen = v;
-            cur = (unsigned)(v ? __builtin_amdgcn_readlane((int)out1, k) : __builtin_amdgcn_readlane((int)out0, k));
-            if (!blocked && lanePix == pix) iorEnd = __uint_as_float(cur);
-        }
-        if (need == 0ull) break;
-        // ---- the lanes that lack a version start it from their snapshots
-        running = ((need >> lane) & 1ull) != 0ull;
-        RZ_GSTAT(3, 1);
-        if (running) {
-            P.color = mk3(0.0f, 0.0f, 0.0f);
-            if (COUNT) att = {};
-            snapshot_load<COUNT>(K, P, COUNT ? att : c);
-            P.ior = __uint_as_float(want);
-            P.samp = samp;
-            scatter<COUNT, true, 0>(K, P, COUNT ? att : c);
-        }
-    }
-    // ---- every lane takes the version its chain chose (a sample that never read currentIor has the one)
-    if (mine) {
-        const float* const R = V + (size_t)chosen * 6 * 64;
-        P.addLight = mk3(R[0], R[64], R[128]);
-        P.addSky = mk3(R[192], R[256], R[320]);
-    }
-    if (COUNT) {        // the unit's tallies are those of the versions its chains chose
-        c = {};
-        if (mine) tally_add(c, chosen ? tv1 : tv0);
-    }
-    P.mode = MODE_DONE;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -904,42 +817,129 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
             }
         }
         // A unit's paths run until they finish or stand in front of their third segment (bounce >= 2).
-        // (one exit, at the end of the body: see blas_walk)
-        // (transparent scenes: ... unless that segment's ray passes the box of an instance with glass in it -- may_hit_glass)
-        bool run = P.mode != MODE_DONE && !(P.mode == MODE_SEGMENT && P.bounce >= RZ_PARK_BOUNCE);
-        bool anyRun = rz_ballot(run) != 0ull;
+        // (transparent scenes: ... unless that segment's ray passes the box of an instance with glass in it -- may_hit_glass --
+        //  and, once a sample of the unit has read currentIor, to their ends: the unit is then resolved in the wave, round after
+        //  round through this same loop -- see "Transparent scenes on the compacting claims" above)
+        bool stopLate = !GLASS || !(COUNT || redo);         // late paths stop to be parked (counting launches and redo claims resolve every unit)
+        // the versions of this lane's sample (GLASS): the currentIor each was run from / left behind (bit patterns: a NaN must
+        // equal itself), bit 0 valid, bit 1 the sample read currentIor; their addends wait in the wave's scratch
+        unsigned key0 = __float_as_uint(iorStart), key1 = 0u, out0 = 0u, out1 = 0u, want = __float_as_uint(iorStart);
+        int info0 = 0, info1 = 0, nextSlot = 0, chosen = 0;
+        bool running = mine;                                // lanes whose version is being computed in this round
+        bool resolved = false;                              // wave-uniform: the unit went through the rounds
+        float iorEnd = iorStart;
+        Tally tv0 = {}, tv1 = {};                           // (counting launches: the tallies of each version's whole run)
+        float* const V = GLASS ? K.snap + (size_t)blockIdx.x * K.snapStride + (size_t)(RZ_SNAP_FIELDS + RZ_SNAP_TALLY) * 64 + lane : nullptr;   // [version][6] rows, this lane's column
 #ifdef RZ_PROF
         c.rnd = 0;
 #endif
-        while (anyRun) {
-            if (run) {
-                HitRec h;
-#ifdef RZ_PROF
-                RZ_SITE(c, 6);
-                const unsigned long long tq0_ = __builtin_amdgcn_s_memtime();
-#endif
-                const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, tu);
-#ifdef RZ_PROF
-                c.rt[c.rnd & 7] += __builtin_amdgcn_s_memtime() - tq0_;
-#endif
-                advance<COUNT, GLASS, GLASS ? 1 : 0>(K, P, found, h, tu);
+        // (every round gives each pixel's first blocked sample the version it lacks: at most 64 rounds per unit; the bound is a backstop)
+        for (int round = 0; round < 200; ++round) {
+            // (one exit, at the end of the body: see blas_walk)
+            bool run, anyRun;
+            {
+                const bool late = stopLate && P.mode == MODE_SEGMENT && P.bounce >= RZ_PARK_BOUNCE;
+                run = P.mode != MODE_DONE && !late;
+                if constexpr (GLASS) { if (stopLate) run = run || may_hit_glass(K, late, P.o, P.d); }
+                anyRun = rz_ballot(run) != 0ull;
             }
+            while (anyRun) {
+                if (run) {
+                    HitRec h;
 #ifdef RZ_PROF
-            if (c.rnd < 7) ++c.rnd;
+                    RZ_SITE(c, 6);
+                    const unsigned long long tq0_ = __builtin_amdgcn_s_memtime();
 #endif
-            const bool late = P.mode == MODE_SEGMENT && P.bounce >= RZ_PARK_BOUNCE;
-            run = P.mode != MODE_DONE && !late;
-            if constexpr (GLASS) run = run || may_hit_glass(K, late, P.o, P.d);
-            anyRun = rz_ballot(run) != 0ull;
+                    const bool found = trace_closest<COUNT, OVF>(K, P.o, P.d, h, bstk, tu);
+#ifdef RZ_PROF
+                    c.rt[c.rnd & 7] += __builtin_amdgcn_s_memtime() - tq0_;
+#endif
+                    advance<COUNT, GLASS, GLASS ? 1 : 0>(K, P, found, h, tu);
+                }
+#ifdef RZ_PROF
+                if (c.rnd < 7) ++c.rnd;
+#endif
+                const bool late = stopLate && P.mode == MODE_SEGMENT && P.bounce >= RZ_PARK_BOUNCE;
+                run = P.mode != MODE_DONE && !late;
+                if constexpr (GLASS) { if (stopLate) run = run || may_hit_glass(K, late, P.o, P.d); }
+                anyRun = rz_ballot(run) != 0ull;
+            }
+            if constexpr (!GLASS) {
+                break;
+            } else {
+                if (stopLate) {
+                    // did a sample of this unit read currentIor?  If not the unit was clean: its late paths are parked
+                    if (rz_ballot(P.usedIor != 0) == 0ull) break;
+                    stopLate = false;
+                    if (rz_ballot(P.mode != MODE_DONE) != 0ull) continue;       // the late paths run to their ends in the wave first
+                }
+                resolved = true;
+                // ---- every lane of this round has its version
+                if (running) {
+                    const unsigned o = __float_as_uint(P.ior);
+                    const int inf = 1 | (P.usedIor ? 2 : 0);
+                    float* const R = V + (size_t)nextSlot * 6 * 64;
+                    R[0] = P.addLight.x; R[64] = P.addLight.y; R[128] = P.addLight.z;
+                    R[192] = P.addSky.x; R[256] = P.addSky.y; R[320] = P.addSky.z;
+                    if (nextSlot == 0) { key0 = want; out0 = o; info0 = inf; if (COUNT) tv0 = cu; }
+                    else { key1 = want; out1 = o; info1 = inf; if (COUNT) tv1 = cu; }
+                    nextSlot ^= 1;
+                }
+                // ---- walk the chains: the lanes that read currentIor, in sample order, on the scalar unit
+                const unsigned long long touch = rz_ballot(mine && (((info0 | info1) & 2) != 0));
+                unsigned long long need = 0ull;
+                int curPix = -1;
+                unsigned cur = 0u;
+                bool blocked = false;
+                iorEnd = iorStart;
+                chosen = 0;
+                for (unsigned long long rest = touch; rest != 0ull; rest &= rest - 1ull) {
+                    const int k = (int)__builtin_ctzll(rest);
+                    const int pix = __builtin_amdgcn_readlane(pixInUnit, k);
+                    if (pix != curPix) { curPix = pix; cur = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(iorStart), k); blocked = false; }
+                    const int i0 = __builtin_amdgcn_readlane(info0, k), i1 = __builtin_amdgcn_readlane(info1, k);
+                    const unsigned k0 = (unsigned)__builtin_amdgcn_readlane((int)key0, k), k1 = (unsigned)__builtin_amdgcn_readlane((int)key1, k);
+                    const bool has0 = (i0 & 1) && k0 == cur, has1 = (i1 & 1) && k1 == cur;
+                    if (!has0 && !has1) {
+                        // this sample was not run from the value its chain arrives with: it is run again; the samples behind it are
+                        // walked on the guess that it leaves the value alone
+                        need |= 1ull << k;
+                        if (lane == k) want = cur;
+                        blocked = true;
+                        continue;
+                    }
+                    const int v = has0 ? 0 : 1;
+                    if (!blocked && lane == k) chosen = v;
+                    cur = (unsigned)(v ? __builtin_amdgcn_readlane((int)out1, k) : __builtin_amdgcn_readlane((int)out0, k));
+                    if (!blocked && pixInUnit == pix) iorEnd = __uint_as_float(cur);
+                }
+                if (need == 0ull) break;
+                // ---- the lanes that lack a version start it from their snapshots (rz_path.h: in front of their first transparent scatter)
+                RZ_GSTAT(3, 1);
+                running = ((need >> lane) & 1ull) != 0ull;
+                if (running) {
+                    P.color = mk3(0.0f, 0.0f, 0.0f);
+                    if (COUNT) cu = {};
+                    snapshot_load<COUNT>(K, P, tu);
+                    P.ior = __uint_as_float(want);
+                    P.samp = K.sampleBase + b * 64 + sampInUnit;
+                    scatter<COUNT, true, 0>(K, P, tu);
+                }
+            }
         }
         if constexpr (GLASS) {
-            // did a sample of this unit read currentIor?  Then (and in counting launches, whose tallies must be those of the final
-            // versions alone, and when a group is rendered again) the unit is resolved here; otherwise it was clean.
-            float iorEnd = iorStart;
             RZ_GSTAT(0, 1);
-            if (COUNT || redo || rz_ballot(P.usedIor != 0) != 0ull) RZ_GSTAT(1, 1);
-            if (COUNT || redo || rz_ballot(P.usedIor != 0) != 0ull)
-                glass_resolve_unit<COUNT, OVF>(K, bstk, P, mine, K.sampleBase + b * 64 + sampInUnit, pixInUnit, iorStart, iorEnd, tu);
+            if (resolved) {
+                RZ_GSTAT(1, 1);
+                // every lane takes the version its chain chose (a sample that never read currentIor has the one)
+                if (mine) {
+                    const float* const R = V + (size_t)chosen * 6 * 64;
+                    P.addLight = mk3(R[0], R[64], R[128]);
+                    P.addSky = mk3(R[192], R[256], R[320]);
+                }
+                if (COUNT) { cu = {}; if (mine) tally_add(cu, chosen ? tv1 : tv0); }      // the unit's tallies are those of the versions its chains chose
+                P.mode = MODE_DONE;
+            }
             if (COUNT) tally_add(c, cu);
             iorCarry = iorEnd;
             if (b == nBatches - 1) addBase[(size_t)g * GF + (size_t)nBatches * 384 + lane] = iorEnd;       // (read at this lane's pixel's first lane by the sums)
