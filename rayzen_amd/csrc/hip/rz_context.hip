@@ -745,7 +745,7 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     if (c->sceneHasTransparency && plan.perClaim > 0) {
         bool on = true;
         if (const char* e = std::getenv("RZ_GLASS_SNAPSHOT")) on = std::atoi(e) != 0;
-        const size_t stride = (size_t)(RZ_SNAP_FIELDS + RZ_SNAP_TALLY + RZ_GVER_ROWS) * 64;
+        const size_t stride = (size_t)(RZ_SNAP_FIELDS + RZ_SNAP_TALLY + RZ_GVER_ROWS) * 64 + (size_t)RZ_GLATE_FIELDS * RZ_GLATE_CAP;
         if (on) {
             rc = ensure(c, c->dSnap, (size_t)plan.grid * stride * sizeof(float));
             if (rc != RZ_OK) return rc;

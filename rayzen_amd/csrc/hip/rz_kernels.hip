@@ -1065,13 +1065,18 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
 // there (it may not read a value that an earlier sample of its pixel, still in the pool, could change) and marks its group,
 // which is put on the wave's redo list instead of being summed when its last path is back.
 template <bool COUNT, bool OVF, bool GLASS>
-__device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restrict__ W, const size_t WS, const int n, const BlasStackT<OVF>& bstk, int& freeCount, int& redoCount) {
+__device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restrict__ W, const size_t WS, const int n, const BlasStackT<OVF>& bstk, int& freeCount, int& redoCount, int& lateN) {
     using namespace poolf;
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
     float* const slotsBase = K.wslots + (size_t)blockIdx.x * K.wslotStride + K.claimScratchFloats;      // (behind the wave's claim scratch)
     int* const meta = K.wmeta + (size_t)blockIdx.x * 4 * K.nWaitSlots;
     const int NS = K.nWaitSlots;
+    const int spp = K.spp, nBatches = (spp + 63) / 64;
+    // transparent scenes: the wave's LATE LIST -- pooled samples that stand in front of a transparent scatter (see below)
+    unsigned* const LL = GLASS ? reinterpret_cast<unsigned*>(K.snap + (size_t)blockIdx.x * K.snapStride + (size_t)(RZ_SNAP_FIELDS + RZ_SNAP_TALLY + RZ_GVER_ROWS) * 64) : nullptr;
+    constexpr int LC = RZ_GLATE_CAP;
+    constexpr unsigned FULL_REDO = 1u << 30;
     Tally c = {};
 #ifdef RZ_PROF
     const unsigned long long tl0_ = __builtin_amdgcn_s_memtime();
@@ -1092,6 +1097,7 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
         P.addSky = mk3(0.0f, 0.0f, 0.0f);
         P.usedIor = 0;
         P.ior = 1.0f;
+        P.gflag = 0;
         unsigned back = 0, wslot = 0;
         if (sl < n) {
             P.o = mk3(__uint_as_float(W[OX * WS + sl]), __uint_as_float(W[OY * WS + sl]), __uint_as_float(W[OZ * WS + sl]));
@@ -1102,7 +1108,11 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
             P.samp = (int)W[SAMP * WS + sl];
             back = W[BACK * WS + sl];
             wslot = W[(size_t)(RZ_GPOOL_FIELDS - 1) * WS + sl];
-            P.bounce = (int)(back >> 16);
+            P.bounce = (int)((back >> 16) & 0x7fffu);
+            if constexpr (GLASS) {      // (bit 31: a released late sample -- its currentIor is the one the sequential shader would hand it)
+                P.gflag = (int)(back >> 31);
+                if (P.gflag) P.ior = __uint_as_float(W[IOR * WS + sl]);
+            }
             P.color = mk3(0.0f, 0.0f, 0.0f);
             P.mode = MODE_SEGMENT;
             const int qTri = (int)W[QTRI * WS + sl];
@@ -1120,14 +1130,38 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
             advance<COUNT, GLASS, GLASS ? 2 : 0>(K, P, found, h, c);      // one segment: sky and the end, or scatter (no shadow queries after bounce 0)
         }
         const bool parked = P.mode != MODE_DONE;
-        if (sl < n && !parked) {           // the path has ended: its sky term (FS:709; zero when it ended by roulette or budget) goes to its sample's place
+        // GLASS: the path stands in front of a transparent scatter and may not read currentIor yet (an earlier sample of its pixel
+        // can still be in the pool).  It waits on the wave's late list -- the state the scatter needs, 19 dwords -- still counted
+        // among its group's outstanding paths, and is RELEASED, earliest sample first, once no other path of the group is in
+        // flight (below).  Groups of several batches per pixel (units resolved in the wave may stand behind it in the chain) and a
+        // full list fall back to rendering the group again.
+        bool met = GLASS && sl < n && !P.gflag && P.usedIor != 0;
+        bool toList = false;
+        if constexpr (GLASS) {
+            const unsigned long long mm = rz_ballot(met);
+            const bool room = nBatches == 1 && lateN + mask_count(mm) <= LC;
+            toList = met && room;
+            if (toList) {
+                const size_t e = (size_t)lateN + __popcll(mm & below);
+                LL[0 * LC + e] = __float_as_uint(P.hp.x); LL[1 * LC + e] = __float_as_uint(P.hp.y); LL[2 * LC + e] = __float_as_uint(P.hp.z);
+                LL[3 * LC + e] = __float_as_uint(P.hn.x); LL[4 * LC + e] = __float_as_uint(P.hn.y); LL[5 * LC + e] = __float_as_uint(P.hn.z);
+                LL[6 * LC + e] = __float_as_uint(P.pdir.x); LL[7 * LC + e] = __float_as_uint(P.pdir.y); LL[8 * LC + e] = __float_as_uint(P.pdir.z);
+                LL[9 * LC + e] = __float_as_uint(P.throughput.x); LL[10 * LC + e] = __float_as_uint(P.throughput.y); LL[11 * LC + e] = __float_as_uint(P.throughput.z);
+                LL[12 * LC + e] = __float_as_uint(P.seed.x); LL[13 * LC + e] = __float_as_uint(P.seed.y);
+                LL[14 * LC + e] = (unsigned)P.samp; LL[15 * LC + e] = (unsigned)P.bounce; LL[16 * LC + e] = (unsigned)P.hmat;
+                LL[17 * LC + e] = back & 0xffffu; LL[18 * LC + e] = wslot;
+                atomicAdd(meta + 2 * NS + wslot, 1);       // the group's samples on the late list
+            }
+            if (room) lateN += mask_count(mm);
+        }
+        if (sl < n && !parked && !toList) {           // the path has ended: its sky term (FS:709; zero when it ended by roulette or budget) goes to its sample's place
             float* const A = slotsBase + (size_t)wslot * K.slotFloats + (size_t)((back >> 6) & 1023u) * 384;
             const unsigned bl = back & 63u;
             A[192 + bl] = P.addSky.x; A[256 + bl] = P.addSky.y; A[320 + bl] = P.addSky.z;
-            if (GLASS && P.usedIor) meta[2 * NS + wslot] = 1;       // it stopped in front of a transparent scatter: its group is rendered again
-#ifdef RZ_GSTATS
-            if (GLASS && P.usedIor) atomicAdd(&rz_gstats[5], 1ull);
-#endif
+            if constexpr (GLASS) {
+                if (met) atomicOr(reinterpret_cast<unsigned*>(meta) + 2 * NS + wslot, FULL_REDO);       // no room on the list: the group is rendered again
+                if (P.gflag) slotsBase[(size_t)wslot * K.slotFloats + (size_t)nBatches * 384 + (spp >= 64 ? 0u : (bl / (unsigned)spp) * (unsigned)spp)] = P.ior;   // what this sample leaves its pixel (FS:742)
+            }
             atomicAdd(meta + NS + wslot, -1);      // (nothing comes back: the wave looks at the counts once, after the shade rounds)
         }
         const unsigned long long pm = rz_ballot(parked);
@@ -1138,8 +1172,9 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
             W[TPX * WS + d] = __float_as_uint(P.throughput.x); W[TPY * WS + d] = __float_as_uint(P.throughput.y); W[TPZ * WS + d] = __float_as_uint(P.throughput.z);
             W[SEEDX * WS + d] = __float_as_uint(P.seed.x); W[SEEDY * WS + d] = __float_as_uint(P.seed.y);
             W[SAMP * WS + d] = (unsigned)P.samp;
-            W[BACK * WS + d] = ((unsigned)P.bounce << 16) | (back & 0xffffu);
+            W[BACK * WS + d] = ((unsigned)P.gflag << 31) | ((unsigned)P.bounce << 16) | (back & 0xffffu);
             W[(size_t)(RZ_GPOOL_FIELDS - 1) * WS + d] = wslot;
+            if constexpr (GLASS) W[IOR * WS + d] = __float_as_uint(P.ior);
         }
         write += mask_count(pm);
     }
@@ -1150,12 +1185,85 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
 #ifdef RZ_PROF
     const unsigned long long tss0_ = __builtin_amdgcn_s_memtime();
 #endif
-    // the groups whose last path has come back in this pass: count 0 (past the L1: the atomics act on the L2)
+    if constexpr (GLASS) {
+        // ---- release: a group none of whose paths is in flight (outstanding == its samples on the late list) lets its EARLIEST
+        // late sample go: the sample takes the currentIor its pixel has reached (the slot's ior row), scatters (FS:723-746) and
+        // goes on through the pool as a path that may read currentIor -- or ends on the spot.  One sample per group and step: the
+        // next one sees what this one leaves.  Repeated until no group can release (a sample that ends on the spot frees the next).
+        for (int step = 0; step < 4 * LC && lateN > 0; ++step) {
+            const int cnt = lane < NS ? wmeta_load(meta + NS + lane) : 0;
+            const unsigned lt = lane < NS ? (unsigned)wmeta_load(meta + 2 * NS + lane) : 0u;
+            const unsigned long long rel = rz_ballot(lane < NS && (lt & 0xffffu) != 0u && cnt == (int)(lt & 0xffffu));
+            if (rel == 0ull) break;
+            for (unsigned long long rest = rel; rest != 0ull; rest &= rest - 1ull) {
+                const int s = (int)__builtin_ctzll(rest);
+                // the group's earliest sample on the list (key = batch << 6 | lane)
+                int best = -1;
+                unsigned bestKey = 0xffffffffu;
+                for (int e0 = 0; e0 < lateN; e0 += 64) {
+                    const int e = e0 + lane;
+                    const bool mine_ = e < lateN && LL[18 * LC + e] == (unsigned)s;
+                    const unsigned key_ = mine_ ? LL[17 * LC + e] : 0xffffffffu;
+                    for (unsigned long long mm = rz_ballot(mine_); mm != 0ull; mm &= mm - 1ull) {
+                        const int l_ = (int)__builtin_ctzll(mm);
+                        const unsigned k_ = (unsigned)__builtin_amdgcn_readlane((int)key_, l_);
+                        if (k_ < bestKey) { bestKey = k_; best = e0 + l_; }
+                    }
+                }
+                if (best < 0) continue;     // (cannot be: the count says the group has samples on the list)
+                Path P;
+                P.mode = MODE_DONE;
+                P.addLight = mk3(0.0f, 0.0f, 0.0f);
+                P.addSky = mk3(0.0f, 0.0f, 0.0f);
+                P.usedIor = 0; P.gflag = 1; P.ior = 1.0f;
+                float* const A = slotsBase + (size_t)s * K.slotFloats;
+                const unsigned bl = bestKey & 63u;
+                const unsigned iorIdx = (unsigned)nBatches * 384u + (spp >= 64 ? 0u : (bl / (unsigned)spp) * (unsigned)spp);
+                if (lane == 0) {
+                    const size_t e = (size_t)best;
+                    P.hp = mk3(__uint_as_float(LL[0 * LC + e]), __uint_as_float(LL[1 * LC + e]), __uint_as_float(LL[2 * LC + e]));
+                    P.hn = mk3(__uint_as_float(LL[3 * LC + e]), __uint_as_float(LL[4 * LC + e]), __uint_as_float(LL[5 * LC + e]));
+                    P.pdir = mk3(__uint_as_float(LL[6 * LC + e]), __uint_as_float(LL[7 * LC + e]), __uint_as_float(LL[8 * LC + e]));
+                    P.throughput = mk3(__uint_as_float(LL[9 * LC + e]), __uint_as_float(LL[10 * LC + e]), __uint_as_float(LL[11 * LC + e]));
+                    P.seed.x = __uint_as_float(LL[12 * LC + e]); P.seed.y = __uint_as_float(LL[13 * LC + e]);
+                    P.samp = (int)LL[14 * LC + e]; P.bounce = (int)LL[15 * LC + e]; P.hmat = (int)LL[16 * LC + e];
+                    P.color = mk3(0.0f, 0.0f, 0.0f);
+                    P.ior = A[iorIdx];
+                    scatter<COUNT, true, 0>(K, P, c);
+                    LL[18 * LC + e] = 0xffffffffu;         // (off the list)
+                    atomicAdd(meta + 2 * NS + s, -1);
+                    if (P.mode != MODE_DONE) {             // it goes on: a pooled path that may read currentIor
+                        const size_t d = (size_t)write;
+                        W[OX * WS + d] = __float_as_uint(P.o.x); W[OY * WS + d] = __float_as_uint(P.o.y); W[OZ * WS + d] = __float_as_uint(P.o.z);
+                        W[DX * WS + d] = __float_as_uint(P.d.x); W[DY * WS + d] = __float_as_uint(P.d.y); W[DZ * WS + d] = __float_as_uint(P.d.z);
+                        W[TPX * WS + d] = __float_as_uint(P.throughput.x); W[TPY * WS + d] = __float_as_uint(P.throughput.y); W[TPZ * WS + d] = __float_as_uint(P.throughput.z);
+                        W[SEEDX * WS + d] = __float_as_uint(P.seed.x); W[SEEDY * WS + d] = __float_as_uint(P.seed.y);
+                        W[SAMP * WS + d] = (unsigned)P.samp;
+                        W[BACK * WS + d] = (1u << 31) | ((unsigned)P.bounce << 16) | bestKey;
+                        W[(size_t)(RZ_GPOOL_FIELDS - 1) * WS + d] = (unsigned)s;
+                        W[IOR * WS + d] = __float_as_uint(P.ior);
+                    } else {                               // it ended at the scatter (bounce budget, roulette): nothing more to add
+                        A[iorIdx] = P.ior;
+                        atomicAdd(meta + NS + s, -1);
+                    }
+                }
+                write += __builtin_amdgcn_readfirstlane(P.mode != MODE_DONE ? 1 : 0);
+            }
+            __syncthreads();
+        }
+        // (the list is emptied when nothing on it is alive: records are few and short-lived)
+        {
+            bool any = false;
+            for (int e0 = 0; e0 < lateN; e0 += 64) any = any || rz_ballot(e0 + lane < lateN && LL[18 * LC + e0 + lane] != 0xffffffffu) != 0ull;
+            if (!any) lateN = 0;
+        }
+    }
+    // the groups whose last path has come back in this pass: slots in use whose count is 0 (read past the L1: the atomics act on the L2)
     unsigned long long ready = rz_ballot(lane < NS && wmeta_load(meta + NS + (lane < NS ? lane : 0)) == 0);
     if constexpr (GLASS) {
-        // ... of them, the groups a path of which met glass: onto the redo list (the wave renders them again before anything
-        // else: rz_render_samples), their slots are free
-        const unsigned long long dirty = ready & rz_ballot(lane < NS && wmeta_load(meta + 2 * NS + (lane < NS ? lane : 0)) == 1);
+        // ... of them, the groups that must be rendered again (a pooled path met glass and could not wait on the list): onto the
+        // redo list (the wave renders them before anything else: rz_render_samples), their slots are free
+        const unsigned long long dirty = ready & rz_ballot(lane < NS && ((unsigned)wmeta_load(meta + 2 * NS + (lane < NS ? lane : 0)) & FULL_REDO) != 0u);
         if ((dirty >> lane) & 1ull) {
             meta[3 * NS + redoCount + __popcll(dirty & below)] = wmeta_load(meta + lane);
             meta[2 * NS + lane] = 0;
@@ -1202,7 +1310,7 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
         int* const meta = K.wmeta + (size_t)blockIdx.x * 4 * K.nWaitSlots;
         if ((int)(threadIdx.x & 63) < K.nWaitSlots) meta[K.nWaitSlots + (threadIdx.x & 63)] = -1;
         __syncthreads();
-        int wpN = 0, freeCount = K.nWaitSlots, redoCount = 0;
+        int wpN = 0, freeCount = K.nWaitSlots, redoCount = 0, lateN = 0;
         const BlasStackT<OVF> bstk{reinterpret_cast<uint2*>(lds_raw) + (threadIdx.x & 63),
                                    OVF ? K.blasOvf + ((size_t)blockIdx.x * K.blasOvfCap) * 64 + (threadIdx.x & 63) : nullptr, K.blasStackCap};
         // (every iteration renders a claim or some redo groups, or ends the wave: the bound is a backstop)
@@ -1221,8 +1329,10 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
                 // slots, after every claim if the launch was told so (RZ_CROSS_CLAIM_POOL=0), and -- generation after generation --
                 // when the claims have run out.  Every pass moves its paths one bounce on and ends some of them: a path survives at
                 // most maxBounces - 1 scatters, and with an empty pool every slot is free (the bound is a backstop).
-                for (int guard = 0; wpN > 0 && (!more || wpN >= (int)K.wpoolChunk || freeCount < need || K.drainEachClaim != 0) && guard <= K.maxBounces + 1; ++guard)
-                    wpN = pool_process<COUNT, OVF, GLASS>(K, K.wpool + (size_t)blockIdx.x * K.wpoolStride * RZ_GPOOL_FIELDS, K.wpoolStride, wpN, bstk, freeCount, redoCount);
+                // (transparent scenes: a group's late samples are released one after the other, each for up to maxBounces passes more)
+                const int maxPasses = (K.maxBounces + 1) * (GLASS ? RZ_GLATE_CAP + 1 : 1);
+                for (int guard = 0; wpN > 0 && (!more || wpN >= (int)K.wpoolChunk || freeCount < need || K.drainEachClaim != 0) && guard <= maxPasses; ++guard)
+                    wpN = pool_process<COUNT, OVF, GLASS>(K, K.wpool + (size_t)blockIdx.x * K.wpoolStride * RZ_GPOOL_FIELDS, K.wpoolStride, wpN, bstk, freeCount, redoCount, lateN);
                 if (!more) {
                     if (GLASS && redoCount > 0) continue;   // the last passes' groups to render again
                     break;

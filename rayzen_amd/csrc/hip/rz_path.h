@@ -54,6 +54,7 @@ struct Path {
     // one-lane-per-sample kernel parks them in LDS and replays the adds in sample order (rz_kernels.hip).
     v3 addLight, addSky;
     int usedIor;        // this sample read (and possibly changed) currentIor: FS:727-742 executed
+    int gflag;          // pooled paths of a transparent scene (GMODE 2): 1 = P.ior is the value the sequential shader would hand this sample (it may scatter at glass)
 };
 
 // FS:204-212 + FS:688-692
@@ -271,7 +272,7 @@ __device__ __forceinline__ void scatter(const KParams& K, Path& P, Tally& c) {
     RZ_T0();
     const DevMaterial M = K.materials[P.hmat];
     if constexpr (GLASS && GMODE == 2) {
-        if (M.transparency > 0.0f) { P.usedIor = 1; P.mode = MODE_DONE; return; }
+        if (M.transparency > 0.0f && !P.gflag) { P.usedIor = 1; P.mode = MODE_DONE; return; }
     }
     if (COUNT) c.scatters += 1;
     const float fb2 = (float)(P.bounce * P.bounce), fb = (float)P.bounce;

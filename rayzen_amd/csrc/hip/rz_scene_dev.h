@@ -141,7 +141,7 @@ struct KParams {
     // ---- transparent scenes, persistent launches: per resident wave, the state of each lane's sample in front of its first
     //      transparent scatter (rz_path.h: snapshot_store), from which the sample's second version starts; null: re-runs start at the camera
     float* snap;            // [resident wave][snapStride] floats
-    uint32_t snapStride;    // >= (RZ_SNAP_FIELDS + RZ_SNAP_TALLY + RZ_GVER_ROWS) * 64
+    uint32_t snapStride;    // >= (RZ_SNAP_FIELDS + RZ_SNAP_TALLY + RZ_GVER_ROWS) * 64 + RZ_GLATE_FIELDS * RZ_GLATE_CAP
 };
 
 // Arguments of the device TLAS rebuild (rz_tlas_device.hip: rz_tlas_refit; filled in by rz_context.hip).
@@ -167,9 +167,10 @@ struct SamplesPlan { long long groups, grid; int perClaim; bool compact; int cla
 
 // The kernel is instantiated for claims of 8 and of 16 units (rz_kernels.hip: plan_render_samples picks by the size of the launch).
 constexpr int RZ_CLAIM_UNITS_SMALL = 8, RZ_CLAIM_UNITS_LARGE = 16;
-constexpr int RZ_POOL_FIELDS = 23;      // the parked path (13), its query (8), the items of a B phase (2): rz_trace.h, namespace poolf
-constexpr int RZ_GPOOL_FIELDS = RZ_POOL_FIELDS + 1;     // a wave's pool: ... + the wait slot of the group a parked path belongs to (field 23)
+constexpr int RZ_POOL_FIELDS = 24;      // the parked path (13), its query (8), the items of a B phase (2), its currentIor (transparent scenes): rz_trace.h, namespace poolf
+constexpr int RZ_GPOOL_FIELDS = RZ_POOL_FIELDS + 1;     // a wave's pool: ... + the wait slot of the group a parked path belongs to (field 24)
 constexpr int RZ_SNAP_FIELDS = 19, RZ_SNAP_TALLY = 14;  // rz_path.h: snapshot_store -- a sample's state in front of its first transparent scatter (+ its tallies, counting launches)
+constexpr int RZ_GLATE_FIELDS = 19, RZ_GLATE_CAP = 128;    // rz_kernels.hip: pool_process -- the pooled samples of a transparent scene that stand in front of a transparent scatter (field-major records behind the version rows)
 constexpr int RZ_GVER_ROWS = 12;        // rz_kernels.hip: glass_resolve_unit -- the two versions of a sample's addends, [version][6] rows of 64 floats behind the snapshot rows
 
 }  // namespace rz

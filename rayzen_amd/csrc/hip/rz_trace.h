@@ -720,9 +720,10 @@ __device__ __forceinline__ bool trace_spread(const KParams& K, v3 o, v3 d, HitRe
 namespace poolf {      // field numbers of the pool (each field is PS consecutive dwords)
 enum : int { OX = 0, OY, OZ, DX, DY, DZ, TPX, TPY, TPZ, SEEDX, SEEDY, SAMP, BACK,      // the parked path (rz_kernels.hip)
              QT = 13, QPX, QPY, QPZ, QTRI, QINST, QIDX, QSUB,                            // its query: tHit, hit point, winner, list position, entry within a multi-instance leaf
-             ITSLOT = 21, ITINST = 22 };                                                 // the items of the current B phase
+             ITSLOT = 21, ITINST = 22,                                                   // the items of the current B phase
+             IOR = 23 };                                                                 // transparent scenes: the currentIor of a path that may read it (rz_kernels.hip: released late samples)
 }
-static_assert(poolf::ITINST + 1 == RZ_POOL_FIELDS, "pool fields");
+static_assert(poolf::IOR + 1 == RZ_POOL_FIELDS, "pool fields");
 
 #ifndef RZ_REFILL_MIN_LANES
 #define RZ_REFILL_MIN_LANES 8      // idle lanes it takes to interrupt the walk for a refill (unless nobody walks at all)
