@@ -860,8 +860,14 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
                 if (c.rnd < 7) ++c.rnd;
 #endif
                 const bool late = stopLate && P.mode == MODE_SEGMENT && P.bounce >= RZ_PARK_BOUNCE;
-                run = P.mode != MODE_DONE && !late;
-                if constexpr (GLASS) { if (stopLate) run = run || may_hit_glass(K, late, P.o, P.d); }
+                if constexpr (GLASS) {
+                    // (a lane that did not run in this trip keeps its ray and its verdict: the boxes are looked at once per ray)
+                    const bool ran = run;
+                    run = P.mode != MODE_DONE && !late;
+                    if (stopLate) run = ran && (run || may_hit_glass(K, ran && late, P.o, P.d));
+                } else {
+                    run = P.mode != MODE_DONE && !late;
+                }
                 anyRun = rz_ballot(run) != 0ull;
             }
             if constexpr (!GLASS) {

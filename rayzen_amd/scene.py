@@ -411,6 +411,22 @@ def reference_scene(aspect=800.0 / 600.0, mesh_n=9):
     return s.build()
 
 
+def hidden_glass_scene(n=76, aspect=16.0 / 9.0):
+    """C2's scene plus ONE transparent triangle far behind the camera: no path ever meets it, but the scene "has a transparent
+    material", so the launch takes the transparent-scene kernels -- what they cost a frame that never needs them."""
+    s = Scene(camera=Camera(position=(0.0, 2.5, 10.0), aspect=aspect))
+    floor = s.add_mesh(make_cube(4))
+    bunny = s.add_mesh(make_blob(n, 2.8, 0))
+    s.add_object(floor, translate(scale(identity(), (8.0, 0.5, 8.0)), (0.0, -3.0, 0.0)))
+    s.add_object(bunny, translate(identity(), (0.0, 2.0, 0.0)))
+    t = np.zeros(1, TRIANGLE)
+    t["v0"], t["v1"], t["v2"] = (0, 0, 0), (0.01, 0, 0), (0, 0.01, 0)
+    t["materialIndex"] = 3
+    s.add_object(s.add_mesh(t), translate(identity(), (0.0, 50.0, 60.0)))
+    s.name = f"bunny{12 * n * n}+hidden-glass-triangle"
+    return s.build()
+
+
 # The named workloads of the measurement scripts (bench_configs.py, profiles/scripts/*): BASELINE.json's configurations on one
 # GPU and their companions.  name -> (scene factory, width, height, spp, bounces).
 NAMED_CONFIGS = {
@@ -421,6 +437,7 @@ NAMED_CONFIGS = {
     "c2close": (lambda: bunny_scene(n=76, aspect=16 / 9, camera_position=CLOSE_CAMERA), 1920, 1080, 64, 4),
     "c2g": (lambda: bunny_scene(n=76, aspect=16 / 9, extras=True), 1920, 1080, 64, 4),       # + a glass blob and a mirror cube
     "glassbunny": (lambda: bunny_scene(n=76, aspect=16 / 9, bunny_material=3), 1920, 1080, 64, 4),
+    "c2hidden": (lambda: hidden_glass_scene(n=76, aspect=16 / 9), 1920, 1080, 64, 4),           # the transparent kernels' pure overhead
     "mirror": (lambda: bunny_scene(n=76, aspect=16 / 9, bunny_material=2, floor_material=2), 1920, 1080, 64, 8),
     "c3": (lambda: bunny_scene(n=76, aspect=16 / 9), 1920, 1080, 256, 4),                    # configs[2]'s frame, whole on one GPU
     "c4": (lambda: instanced_scene(n=76, count=16, aspect=16 / 9), 1920, 1080, 16, 4),
