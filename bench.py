@@ -40,7 +40,7 @@ SIMDS = 256 * 4                 # 256 CUs x 4 SIMD-32
 MAX_CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md "Max clock"
 ISSUE_CYCLES_PER_INST = 2.0     # a SIMD issues at most one wave64 instruction per 2 cycles (profiles/r02_valu_issue)
 ISSUE_PEAK_GINST = SIMDS * MAX_CLOCK_HZ / ISSUE_CYCLES_PER_INST / 1e9
-PMC_JSON = os.path.join(ROOT, "profiles", "r03_c2_kernel", "pmc_rz_render_samples.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r04_c2_kernel", "pmc_rz_render_samples.json")
 # Measured issue cost (SIMD cycles per wave64 instruction with four waves resident, profiles/r02_valu_issue/valu_issue.txt)
 # of the VALU classes the SQ counters tell apart; "other" = comparisons, selects, min / max, moves, lane reads.  The f32
 # add / mul / fma class mixes 2-cycle scalar-free forms with 3.5-cycle packed and SGPR-operand forms (2.6 assumed), int32

@@ -28,7 +28,7 @@ DEFAULT_GROUPS = [
     # the instruction cache (a 99-KB kernel whose waves sit in different phases); one pass of their own, so
     # that a build of rocprofv3 that lacks one of the names loses only this pass
     "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE",
-    "SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAIT_IFETCH",
+    "SQ_IFETCH SQ_IFETCH_LEVEL",
 ]
 
 

@@ -45,4 +45,19 @@ for _ in range(3):
 r.sync()
 share = min(r.render_history_ms()[1:])
 print(f"C3: whole 256-spp frame on one GPU {full:.3f} ms (1/8 = {full / 8:.3f}); rank 0 of 8: {share:.3f} ms", flush=True)
+# STRONG scaling of C2 itself: the 64-spp frame split over N ranks -- rank 0's share against 1/N of the frame
+r.set_frame(frame_params(sc.camera, W, H, len(sc.lights), B, 64, 0, 0, 1))
+for _ in range(3):
+    r.render()
+r.sync()
+full64 = min(r.render_history_ms()[1:])
+for n in (2, 4, 8):
+    r.set_frame(frame_params(sc.camera, W, H, len(sc.lights), B, 64, 0, 0, n))
+    for _ in range(4):
+        r.render()
+    r.sync()
+    sh = min(r.render_history_ms()[1:])
+    plan = r.debug_last_plan()
+    print(f"C2 strong, N={n}: whole frame {full64:.3f} ms (1/{n} = {full64 / n:.3f}); rank 0 of {n}: {sh:.3f} ms = {full64 / n / sh:.2f} of ideal; "
+          f"claims of {plan['claim_units']} units, {plan['per_claim']} groups", flush=True)
 r.close()
