@@ -6,7 +6,7 @@
 
 One "step" = one pass of the hot path over one frame of synthetic input: BASELINE.json configs[1], the
 ~69k-triangle "bunny" scene (procedural stand-in, see rayzen_amd/scene.py) at 1920x1080, 4 bounces, 64 samples per
-pixel per GPU.  At N > 1 the frame's 8x8-pixel tiles are dealt round-robin to the ranks and ONE RCCL reduce(SUM) per
+pixel per GPU.  At N > 1 the frame's 8x8-pixel tiles are dealt round-robin to the ranks and ONE exchange step (a gather of the ranks' own tiles over RCCL; RZ_GROUP_TRANSPORT=reduce: a reduce(SUM)) per
 step lands the frame on rank 0 -- both through the C-ABI's multi-GPU group (include/rayzen_hip.h: rz_group_*), the
 reduce enqueued on each member's render stream.  Two ways to start it:
   * `python bench.py --gpus N` as ONE plain process (no launcher, WORLD_SIZE unset): rz_group_create(N) -- N contexts on
@@ -100,6 +100,10 @@ def parse(argv=None):
                          "ranks' device buffers (backend nccl = RCCL; also the automatic fallback if the group cannot be formed); "
                          "torch-gloo = rehearsal of the N>1 code path on a box with fewer GPUs than ranks (ranks share devices, "
                          "reduce staged through the host)")
+    ap.add_argument("--loopback", action="store_true",
+                    help="REHEARSAL of `--gpus N` as one plain process on a box with fewer GPUs: the N members of the group share "
+                         "device 0 and device copies stand in for the links (RZ_GROUP_LOOPBACK); everything else -- the dealing of "
+                         "tiles, packing, the root's scatter, the timing -- is the code an N-GPU run executes.  Not a scaling number.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="oracle threads (default: min(16, usable cores) = the box's CPU share)")
     ap.add_argument("--cpu-bands", type=int, default=36, help="oracle sample: this many 8-row bands of the frame")
@@ -139,7 +143,9 @@ def main(argv=None):
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     if mode == "local-group" and a.reduce != "group":
         raise SystemExit("--reduce torch / torch-gloo need one process per GPU: start bench.py with torch.distributed.run")
-    if mode == "local-group" and ndev < world:
+    if a.loopback and mode != "local-group":
+        raise SystemExit("--loopback rehearses `--gpus N` (N > 1) started as one plain process")
+    if mode == "local-group" and ndev < world and not a.loopback:
         raise SystemExit(f"--gpus {world} but only {ndev} HIP device(s) are visible to this process")
 
     torch = dist = dev = None
@@ -170,7 +176,8 @@ def main(argv=None):
     group = None
     if mode == "local-group":
         # ONE process, N devices: the library makes the contexts and the communicators (ncclCommInitAll)
-        group = rzdist.Group.create(world, None, flags)
+        group = (rzdist.Group.create(world, [0] * world, flags | rzdist.GROUP_LOOPBACK) if a.loopback
+                 else rzdist.Group.create(world, None, flags))
     elif use_group:
         # Two steps, so that a rank which cannot even bind RCCL or make its context never leaves the others waiting inside
         # ncclCommInitRank: (1) every rank probes, all agree; (2) rank 0 makes the communicator id, everybody receives it over
@@ -234,7 +241,7 @@ def main(argv=None):
     def step():
         if group is not None:
             group.render()                  # asynchronous on the members' streams
-            group.reduce(0)                 # ONE ncclReduce(sum) of the 33 MB frame per member, enqueued behind its kernel
+            group.reduce(0)                 # the frame's exchange step (tile gather: 1 / N of the 33-MB frame per member), enqueued behind the kernels
             return
         r.render()
         if mode == "ranks":
@@ -313,15 +320,17 @@ def main(argv=None):
                    "camera": {"position": [float(x) for x in cam.position], "target_dir": [float(x) for x in cam.target],
                               "fov_deg": cam.fov}, "mesh_radius": 2.8, "mesh_centre": [0.0, 2.0, 0.0],
                    "floor": "cube scaled (8, 0.5, 8) at y = -3 (main.cpp:378)",
-                   "parallelism": f"tiles8x8-roundrobin-x{world}" + ((("+rz_group-rccl-reduce(" + ("one process, ncclCommInitAll" if mode == "local-group" else "one process per GPU, ncclCommInitRank") + ")")
+                   "parallelism": f"tiles8x8-roundrobin-x{world}" + ((("+rz_group-" + group.transport + "(" + (("one process, no communicator" if a.loopback else "one process, ncclCommInitAll") if mode == "local-group" else "one process per GPU, ncclCommInitRank") + ")")
                                                                      if use_group else ("+torch-rccl-reduce" if use_nccl else "+gloo-reduce(rehearsal)")) if world > 1 else "")},
     }
     if world > 1:
         # what RCCL saw: the size of the library's communicator (0: the reduce went through torch.distributed instead), and
         # the GPU time of the LAST timed step's reduce by HIP events on the root's stream -- it starts when the root's own
-        # kernel ends, so it holds the wait for the slowest rank as well as the 33-MB transfer
+        # kernel ends, so it holds the wait for the slowest rank as well as the transfer (tile gather: 1 / N of the 33-MB
+        # frame per member, straight to the root; RZ_GROUP_TRANSPORT=reduce: one ncclReduce of the whole buffers)
         out["rccl_ranks"] = group.size if group is not None else 0
-        out["launch"] = mode
+        out["transport"] = group.transport if group is not None else "torch.distributed.reduce"
+        out["launch"] = mode + ("(loopback REHEARSAL: all members on device 0 -- not a scaling number)" if a.loopback else "")
         if reduce_ms is not None:
             out["reduce_ms"] = round(reduce_ms[0] if reduce_ms[0] >= 0 else reduce_ms[1], 3)
             out["reduce_ms_note"] = "HIP events around rz_group_reduce on the root member's stream (last timed step)"

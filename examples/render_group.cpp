@@ -1,5 +1,5 @@
 // render_group.cpp -- the frontend of render_scene.cpp on ALL GPUs of the node, one process: tiles sharded round-robin
-// over the devices, one RCCL reduce(SUM) per frame onto device 0 (include/rayzen_hip.h: rz_group_*).  Also renders the
+// over the devices, one exchange step per frame (the members' tiles gathered over RCCL) onto device 0 (include/rayzen_hip.h: rz_group_*).  Also renders the
 // same frame on a single context and checks that the two images are bit-identical (they must be: disjoint tiles,
 // zeros elsewhere).
 //

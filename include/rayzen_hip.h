@@ -298,15 +298,18 @@ int rz_debug_fail_alloc(rz_ctx* ctx, int nth);
 void* rz_stream_handle(rz_ctx* ctx);
 
 /* ------------------------------------------------------------------------ */
-/* Multi-GPU group: tile-sharded rendering + ONE RCCL reduce per frame.       */
+/* Multi-GPU group: tile-sharded rendering + ONE exchange step per frame.     */
 /* ------------------------------------------------------------------------ */
 /* The reference is single-GPU: its context lifetime is glfwCreateWindow / glfwMakeContextCurrent (main.cpp:228-241)
  * and the teardown at main.cpp:681-686.  A group is that lifetime for N GPUs of one node: it owns one rz_ctx per LOCAL
  * device and the RCCL communicator(s), gives member m the tiles t with t % nranks == rank(m) (rz_frame_params.tile_rank
- * / tile_nranks are filled in by the group), and lands the frame on the root rank with ONE ncclReduce(SUM) of the
- * RGBA32F accumulation buffer over xGMI, issued on the members' render streams (no host synchronisation between the
- * render kernel and the collective).  Tile sets are disjoint and non-owned pixels are zero, so the sum adds each
- * pixel's single value to zeros: the reduced frame is bit-identical to a single-GPU frame.
+ * / tile_nranks are filled in by the group), and lands the frame on the root rank with ONE exchange step over xGMI,
+ * issued on the members' render streams (no host synchronisation between the render kernel and the exchange): by
+ * default a TILE GATHER -- every member packs the tiles it owns (1 / N of the frame) and sends them straight to the
+ * root (ncclSend / ncclRecv), which scatters the N sets into the frame; bits are copied, never added.  With
+ * RZ_GROUP_TRANSPORT=reduce in the environment (and when the bound RCCL lacks ncclSend / ncclRecv) it is ONE
+ * ncclReduce(SUM) of the whole RGBA32F accumulation buffers: tile sets are disjoint and non-owned pixels are zero, so
+ * the sum adds each pixel's single value to zeros.  Either way the frame is bit-identical to a single-GPU frame.
  *
  * Two ways to form a group:
  *   rz_group_create       one process drives ndev devices (ncclCommInitAll); ranks = 0..ndev-1, all local.
@@ -319,6 +322,10 @@ void* rz_stream_handle(rz_ctx* ctx);
  * $RZ_RCCL_LIBRARY, else /opt/rocm/lib/librccl.so.1.  rz_group_rccl_version() reports what was bound (no GPU needed). */
 typedef struct rz_group rz_group;
 #define RZ_GROUP_ID_BYTES 128
+/* rz_group_create only, or-ed into `flags`: a REHEARSAL group -- `devices` may name a device more than once (N ranks on
+ * one GPU), no communicator is made and device-to-device copies stand in for the links.  Everything else (the dealing
+ * of tiles, packing, the root's scatter, stream ordering) is the code an N-GPU group runs. */
+#define RZ_GROUP_LOOPBACK 0x10000u
 int       rz_group_rccl_version(int* version);                 /* binds RCCL; *version = ncclGetVersion() */
 int       rz_group_unique_id(void* id128);                      /* ncclGetUniqueId into RZ_GROUP_ID_BYTES bytes */
 rz_group* rz_group_create(int ndev, const int* devices, unsigned flags);        /* devices NULL: 0..ndev-1 */
@@ -326,6 +333,7 @@ rz_group* rz_group_create_rank(int device, int rank, int nranks, const void* id1
 void      rz_group_destroy(rz_group* g);
 const char* rz_group_last_error(const rz_group* g);             /* g NULL: the error of a failed create */
 int       rz_group_size(const rz_group* g);                     /* ranks in the communicator */
+const char* rz_group_transport(const rz_group* g);              /* how rz_group_reduce moves the frame: "tile-gather(...)" | "rccl-reduce" */
 int       rz_group_local_count(const rz_group* g);              /* members owned by this process */
 int       rz_group_rank(const rz_group* g, int local);          /* global rank of local member `local` */
 rz_ctx*   rz_group_ctx(rz_group* g, int local);                 /* the member's context (for per-device calls) */
@@ -336,9 +344,9 @@ int rz_group_update(rz_group* g, rz_binding binding, size_t offset, const void* 
 int rz_group_set_frame(rz_group* g, const rz_frame_params* params);
 /* glDrawArrays on every local member: asynchronous, each on its own device and stream. */
 int rz_group_render(rz_group* g);
-/* ONE ncclReduce(sum, float, width*height*4) per member, enqueued on the member's stream behind its render kernel,
- * from the member's accumulation buffer into the root member's frame buffer (out of place: nobody's accumulation
- * buffer is overwritten, so frames can be continued with sample_base > 0). */
+/* The frame's exchange step (tile gather or ncclReduce, see above), enqueued on every member's stream behind its render
+ * kernel, from the members' accumulation buffers into the root member's frame buffer (out of place: nobody's
+ * accumulation buffer is overwritten, so frames can be continued with sample_base > 0). */
 int rz_group_reduce(rz_group* g, int root);
 int rz_group_sync(rz_group* g);                                 /* glFinish on every local member */
 /* GPU time of the last rz_group_reduce, from HIP events recorded on each local member's stream just before and just

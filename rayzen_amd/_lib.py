@@ -20,7 +20,7 @@ HIP_SYMBOLS = (
     "rz_group_rccl_version", "rz_group_unique_id", "rz_group_create", "rz_group_create_rank", "rz_group_destroy",
     "rz_group_last_error", "rz_group_size", "rz_group_local_count", "rz_group_rank", "rz_group_ctx", "rz_group_upload",
     "rz_group_update", "rz_group_set_frame", "rz_group_render", "rz_group_reduce", "rz_group_sync", "rz_group_read_frame",
-    "rz_group_frame_device_ptr", "rz_group_last_reduce_ms",
+    "rz_group_frame_device_ptr", "rz_group_last_reduce_ms", "rz_group_transport",
 )
 # the symbols include/rayzen_host.h declares
 HOST_SYMBOLS = (
@@ -142,6 +142,7 @@ def hip():
         L.rz_group_frame_device_ptr.restype, L.rz_group_frame_device_ptr.argtypes = vp, [vp]
         try:
             L.rz_group_last_reduce_ms.restype, L.rz_group_last_reduce_ms.argtypes = i, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+            L.rz_group_transport.restype, L.rz_group_transport.argtypes = C.c_char_p, [vp]
         except AttributeError:      # an A/B library built from an older revision (RAYZEN_HIP_SO): everything else still works
             if not os.environ.get("RAYZEN_HIP_SO"):
                 raise

@@ -1,10 +1,15 @@
-// rz_group.hip -- the multi-GPU group of include/rayzen_hip.h: N contexts, tile-sharded, ONE RCCL reduce per frame.
+// rz_group.hip -- the multi-GPU group of include/rayzen_hip.h: N contexts, tile-sharded, ONE exchange step per frame.
 //
 // RayZen is single-GPU; what this replaces is its context lifetime (RayZen/src/main.cpp:228-241 create,
 // :681-686 teardown) for N devices of one node.  Pixels shard by 8x8 tiles dealt round-robin (tile t -> rank t % N,
 // rz_frame_params.tile_rank / tile_nranks); each member renders ALL samples of its own pixels (currentIor couples a
-// pixel's samples, fragment_shader.glsl:674) into a buffer that is zero wherever it owns nothing, and one
-// ncclReduce(sum) over xGMI lands the frame on the root.  The sum adds one value to zeros: bit-identical to one GPU.
+// pixel's samples, fragment_shader.glsl:674) into a buffer that is zero wherever it owns nothing.  The frame lands on the
+// root by a TILE GATHER (round 4, the default): every member packs the tiles it owns (1 KB each, 1 / N of the frame), sends
+// them straight to the root (ncclSend / ncclRecv: xGMI is point to point, the root has a link to every peer, and the seven
+// transfers of an 8-GPU node run side by side), and the root scatters the N packed sets into the frame.  At 1080p on 8 GPUs a
+// member moves 4.1 MB instead of taking part in a 33-MB ring reduce of which 7 / 8 is zeros.  Bits are copied, never added:
+// bit-identical to one GPU.  RZ_GROUP_TRANSPORT=reduce keeps rounds 1-3's ncclReduce(sum) of the whole buffers (one value
+// added to zeros: the same bits), and is what a group falls back to when the bound RCCL has no ncclSend / ncclRecv.
 //
 // RCCL is bound with dlopen when the first group is made: librayzen_hip.so carries no DT_NEEDED on the 570-MB librccl,
 // a process that already has an RCCL mapped (e.g. through torch.distributed) shares that copy instead of running two
@@ -36,6 +41,8 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;      // (optional: the tile gather)
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -82,6 +89,7 @@ int bind_rccl(std::string* err) {
                         bind(h, "ncclGroupEnd", r.GroupEnd) && bind(h, "ncclReduce", r.Reduce) &&
                         bind(h, "ncclGetErrorString", r.GetErrorString);
         if (!ok) { last = t.first + ": an ncclXxx entry point is missing"; dlclose(h); continue; }
+        if (!(bind(h, "ncclSend", r.Send) && bind(h, "ncclRecv", r.Recv))) { r.Send = nullptr; r.Recv = nullptr; }
         g_rccl = r;
         return RZ_OK;
     }
@@ -104,6 +112,16 @@ struct rz_group {
     // HIP events on each member's stream around its share of the last rz_group_reduce (rz_group_last_reduce_ms)
     std::vector<hipEvent_t> evBefore, evAfter;
     bool reduceTimed = false;
+    // the tile gather: each member's packed tiles (on its device), the root's N packed sets (on the root's device)
+    bool gather = true;                 // false: ncclReduce of the whole buffers
+    bool loopback = false;              // RZ_GROUP_LOOPBACK: members share devices, device copies instead of RCCL
+    std::vector<void*> packed;
+    std::vector<size_t> packedBytes;
+    std::vector<hipEvent_t> evSent;     // loopback: a member's packed tiles have reached the root's buffer
+    hipEvent_t evScattered = nullptr;   // loopback: the root has read the gathered sets of the last frame
+    void* gathered = nullptr;
+    size_t gatheredBytes = 0;
+    int gatheredLocal = -1;
     int width = 0, height = 0;
     bool haveFrame = false;
     std::string err;
@@ -132,16 +150,144 @@ int local_of_rank(const rz_group* g, int r) {
     return -1;
 }
 
+// Tile t of the frame (8 x 8 pixels, row-major over the tile grid) belongs to rank t % N and is that rank's local tile t / N
+// (the dealing of rz_frame_params.tile_rank / tile_nranks).  A packed set is a rank's local tiles in order, 64 float4 each,
+// pixel l of a tile at (l & 7, l >> 3); pixels beyond the frame's edge and tiles beyond the last one are zeros.
+__global__ void rz_pack_tiles(const float4* __restrict__ accum, float4* __restrict__ packed, int width, int height, int tilesX, int nTiles,
+                              int rank, int nranks, int perRank) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= perRank * 64) return;
+    const int lt = idx >> 6, l = idx & 63;
+    const int tile = lt * nranks + rank;
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (tile < nTiles) {
+        const int ty = tile / tilesX, tx = tile - ty * tilesX;
+        const int px = tx * 8 + (l & 7), py = ty * 8 + (l >> 3);
+        if (px < width && py < height) v = accum[(size_t)py * width + px];
+    }
+    packed[idx] = v;
+}
+
+__global__ void rz_unpack_tiles(const float4* __restrict__ gathered, float4* __restrict__ frame, int width, int height, int tilesX,
+                                int nranks, int perRank) {
+    const int px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y;
+    if (px >= width || py >= height) return;
+    const int tile = (py >> 3) * tilesX + (px >> 3);
+    const int r = tile % nranks, lt = tile / nranks;
+    frame[(size_t)py * width + px] = gathered[((size_t)r * perRank + lt) * 64 + ((py & 7) << 3 | (px & 7))];
+}
+
+bool transport_is_gather() {
+    const char* e = std::getenv("RZ_GROUP_TRANSPORT");
+    return !(e && std::strcmp(e, "reduce") == 0);
+}
+
 void destroy_members(rz_group* g) {
     for (size_t i = 0; i < g->comm.size(); ++i)
         if (g->comm[i]) { (void)hipSetDevice(g->device[i]); (void)g_rccl.CommDestroy(g->comm[i]); }
     if (g->frame && g->frameLocal >= 0) { (void)hipSetDevice(g->device[g->frameLocal]); (void)hipFree(g->frame); }
+    if (g->gathered && g->gatheredLocal >= 0) { (void)hipSetDevice(g->device[g->gatheredLocal]); (void)hipFree(g->gathered); }
+    for (size_t i = 0; i < g->packed.size(); ++i)
+        if (g->packed[i]) { (void)hipSetDevice(g->device[i]); (void)hipFree(g->packed[i]); }
+    for (size_t i = 0; i < g->evSent.size(); ++i)
+        if (g->evSent[i]) { (void)hipSetDevice(g->device[i]); (void)hipEventDestroy(g->evSent[i]); }
+    if (g->evScattered) (void)hipEventDestroy(g->evScattered);
     for (size_t i = 0; i < g->evBefore.size(); ++i) {
         (void)hipSetDevice(g->device[i]);
         if (g->evBefore[i]) (void)hipEventDestroy(g->evBefore[i]);
         if (g->evAfter[i]) (void)hipEventDestroy(g->evAfter[i]);
     }
     for (rz_ctx* c : g->ctx) rz_destroy(c);
+}
+
+// The tile gather of one frame (see the head of this file): pack on every local member, move, scatter on the root.
+// Everything is enqueued on the members' render streams, behind their kernels; nothing waits on the host.
+int gather_tiles(rz_group* g, int root, int rl) {
+    const int W = g->width, H = g->height, N = g->nranks;
+    const int tilesX = (W + 7) / 8, tilesY = (H + 7) / 8, nTiles = tilesX * tilesY;
+    const int perRank = (nTiles + N - 1) / N;
+    const size_t setFloats = (size_t)perRank * 64 * 4, setBytes = setFloats * sizeof(float);
+    if (g->packed.size() != g->ctx.size()) {
+        g->packed.assign(g->ctx.size(), nullptr);
+        g->packedBytes.assign(g->ctx.size(), 0);
+        g->evSent.assign(g->ctx.size(), nullptr);
+    }
+    if (rl >= 0 && (g->gatheredLocal != rl || g->gatheredBytes < setBytes * N)) {
+        if (g->gathered) { RZG_HIP(g, hipSetDevice(g->device[g->gatheredLocal])); (void)hipFree(g->gathered); g->gathered = nullptr; g->gatheredBytes = 0; }
+        RZG_HIP(g, hipSetDevice(g->device[rl]));
+        RZG_HIP(g, hipMalloc(&g->gathered, setBytes * N));
+        g->gatheredBytes = setBytes * N;
+        g->gatheredLocal = rl;
+    }
+    // (1) pack: the root member straight into its place among the gathered sets, the others into a buffer of their own
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        RZG_HIP(g, hipSetDevice(g->device[i]));
+        hipStream_t s = static_cast<hipStream_t>(rz_stream_handle(g->ctx[i]));
+        void* dst;
+        if ((int)i == rl) {
+            dst = static_cast<char*>(g->gathered) + setBytes * (size_t)root;
+        } else {
+            if (g->packedBytes[i] < setBytes) {
+                if (g->packed[i]) { (void)hipFree(g->packed[i]); g->packed[i] = nullptr; g->packedBytes[i] = 0; }
+                RZG_HIP(g, hipMalloc(&g->packed[i], setBytes));
+                g->packedBytes[i] = setBytes;
+            }
+            dst = g->packed[i];
+        }
+        const float4* accum = static_cast<const float4*>(rz_accum_device_ptr(g->ctx[i]));
+        if (!accum) return member_fail(g, (int)i, RZ_ERR_NOT_READY, "rz_accum_device_ptr");
+        const int threads = perRank * 64;
+        rz_pack_tiles<<<(threads + 255) / 256, 256, 0, s>>>(accum, static_cast<float4*>(dst), W, H, tilesX, nTiles, g->rank[i], N, perRank);
+        RZG_HIP(g, hipGetLastError());
+    }
+    // (2) move: every other member's set to its place on the root
+    if (g->loopback) {
+        for (size_t i = 0; i < g->ctx.size(); ++i) {
+            if ((int)i == rl) continue;
+            RZG_HIP(g, hipSetDevice(g->device[i]));
+            hipStream_t s = static_cast<hipStream_t>(rz_stream_handle(g->ctx[i]));
+            if (!g->evSent[i]) RZG_HIP(g, hipEventCreateWithFlags(&g->evSent[i], hipEventDisableTiming));
+            if (g->evScattered) RZG_HIP(g, hipStreamWaitEvent(s, g->evScattered, 0));        // (the root is through with the last frame's sets)
+            RZG_HIP(g, hipMemcpyAsync(static_cast<char*>(g->gathered) + setBytes * (size_t)g->rank[i], g->packed[i], setBytes, hipMemcpyDeviceToDevice, s));
+            RZG_HIP(g, hipEventRecord(g->evSent[i], s));
+        }
+        RZG_HIP(g, hipSetDevice(g->device[rl]));
+        for (size_t i = 0; i < g->ctx.size(); ++i)
+            if ((int)i != rl) RZG_HIP(g, hipStreamWaitEvent(static_cast<hipStream_t>(rz_stream_handle(g->ctx[rl])), g->evSent[i], 0));
+    } else if (N > 1) {
+        // one group of point-to-point calls: a send per non-root member, N - 1 receives on the root (local members included:
+        // a one-process group's communicators talk to one another like any others)
+        RZG_NCCL(g, g_rccl.GroupStart());
+        for (size_t i = 0; i < g->ctx.size(); ++i) {
+            hipError_t e = hipSetDevice(g->device[i]);
+            hipStream_t s = static_cast<hipStream_t>(rz_stream_handle(g->ctx[i]));
+            ncclResult_t r = e == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+            if ((int)i == rl) {
+                for (int peer = 0; peer < N && r == ncclSuccess; ++peer)
+                    if (peer != root)
+                        r = g_rccl.Recv(static_cast<char*>(g->gathered) + setBytes * (size_t)peer, setFloats, ncclFloat, peer, g->comm[i], s);
+            } else if (r == ncclSuccess) {
+                r = g_rccl.Send(g->packed[i], setFloats, ncclFloat, root, g->comm[i], s);
+            }
+            if (r != ncclSuccess) {
+                (void)g_rccl.GroupEnd();
+                return gfail(&g->err, RZ_ERR_HIP, "ncclSend / ncclRecv on rank %d: %s", g->rank[i], g_rccl.GetErrorString(r));
+            }
+        }
+        RZG_NCCL(g, g_rccl.GroupEnd());
+    }
+    // (3) scatter on the root: every pixel of the frame from its owner's set
+    if (rl >= 0) {
+        RZG_HIP(g, hipSetDevice(g->device[rl]));
+        hipStream_t s = static_cast<hipStream_t>(rz_stream_handle(g->ctx[rl]));
+        rz_unpack_tiles<<<dim3((W + 127) / 128, H), 128, 0, s>>>(static_cast<const float4*>(g->gathered), static_cast<float4*>(g->frame), W, H, tilesX, N, perRank);
+        RZG_HIP(g, hipGetLastError());
+        if (g->loopback) {
+            if (!g->evScattered) RZG_HIP(g, hipEventCreateWithFlags(&g->evScattered, hipEventDisableTiming));
+            RZG_HIP(g, hipEventRecord(g->evScattered, s));
+        }
+    }
+    return RZ_OK;
 }
 
 }  // namespace
@@ -181,21 +327,27 @@ rz_group* rz_group_create(int ndev, const int* devices, unsigned flags) {
         if (ndev <= 0 || ndev > 64) { gfail(nullptr, RZ_ERR_INVALID_ARG, "rz_group_create: ndev %d", ndev); return nullptr; }
         int have = 0;
         if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) { gfail(nullptr, RZ_ERR_NO_DEVICE, "no HIP device"); return nullptr; }
+        const bool loopback = (flags & RZ_GROUP_LOOPBACK) != 0u;
+        flags &= ~RZ_GROUP_LOOPBACK;
+        if (loopback && !devices) { gfail(nullptr, RZ_ERR_INVALID_ARG, "rz_group_create: a loopback group names its devices"); return nullptr; }
         for (int i = 0; i < ndev; ++i) {
             const int d = devices ? devices[i] : i;
             if (d < 0 || d >= have) { gfail(nullptr, RZ_ERR_INVALID_ARG, "rz_group_create: device %d of %d", d, have); return nullptr; }
-            for (int j = 0; j < i; ++j)
+            for (int j = 0; j < i && !loopback; ++j)
                 if ((devices ? devices[j] : j) == d) { gfail(nullptr, RZ_ERR_INVALID_ARG, "rz_group_create: device %d listed twice (one rank per device)", d); return nullptr; }
         }
-        if (bind_rccl(nullptr) != RZ_OK) return nullptr;
+        if (!loopback && bind_rccl(nullptr) != RZ_OK) return nullptr;
         g = new rz_group();
         g->nranks = ndev;
+        g->loopback = loopback;
+        g->gather = loopback || (transport_is_gather() && g_rccl.Send && g_rccl.Recv);
         for (int i = 0; i < ndev; ++i) {
             const int d = devices ? devices[i] : i;
             rz_ctx* c = rz_create(d, flags);
             if (!c) { gfail(nullptr, RZ_ERR_HIP, "rz_group_create: device %d: %s", d, rz_last_error(nullptr)); destroy_members(g); delete g; return nullptr; }
             g->ctx.push_back(c); g->rank.push_back(i); g->device.push_back(d); g->comm.push_back(nullptr);
         }
+        if (loopback) return g;         // (no communicator: device copies stand in for the links)
         ncclResult_t r = g_rccl.CommInitAll(g->comm.data(), ndev, g->device.data());
         if (r != ncclSuccess) {
             gfail(nullptr, RZ_ERR_HIP, "ncclCommInitAll(%d): %s", ndev, g_rccl.GetErrorString(r));
@@ -216,11 +368,13 @@ rz_group* rz_group_create_rank(int device, int rank, int nranks, const void* id1
     try {
         if (nranks <= 0 || rank < 0 || rank >= nranks) { gfail(nullptr, RZ_ERR_INVALID_ARG, "rz_group_create_rank: rank %d of %d", rank, nranks); return nullptr; }
         if (!id128) { gfail(nullptr, RZ_ERR_INVALID_ARG, "rz_group_create_rank: null id"); return nullptr; }
+        if (flags & RZ_GROUP_LOOPBACK) { gfail(nullptr, RZ_ERR_INVALID_ARG, "rz_group_create_rank: RZ_GROUP_LOOPBACK is for rz_group_create"); return nullptr; }
         if (bind_rccl(nullptr) != RZ_OK) return nullptr;
         rz_ctx* c = rz_create(device, flags);
         if (!c) { gfail(nullptr, RZ_ERR_HIP, "rz_group_create_rank: device %d: %s", device, rz_last_error(nullptr)); return nullptr; }
         g = new rz_group();
         g->nranks = nranks;
+        g->gather = transport_is_gather() && g_rccl.Send && g_rccl.Recv;
         g->ctx.push_back(c); g->rank.push_back(rank); g->device.push_back(device); g->comm.push_back(nullptr);
         ncclUniqueId id;
         std::memcpy(&id, id128, sizeof id);
@@ -247,6 +401,10 @@ void rz_group_destroy(rz_group* g) {
 }
 
 int rz_group_size(const rz_group* g) { return g ? g->nranks : 0; }
+const char* rz_group_transport(const rz_group* g) {
+    if (!g) return "";
+    return !g->gather ? "rccl-reduce" : (g->loopback ? "tile-gather(loopback copies)" : "tile-gather(rccl send/recv)");
+}
 int rz_group_local_count(const rz_group* g) { return g ? (int)g->ctx.size() : 0; }
 int rz_group_rank(const rz_group* g, int local) { return (g && local >= 0 && local < (int)g->rank.size()) ? g->rank[local] : -1; }
 rz_ctx* rz_group_ctx(rz_group* g, int local) { return (g && local >= 0 && local < (int)g->ctx.size()) ? g->ctx[local] : nullptr; }
@@ -320,22 +478,27 @@ int rz_group_reduce(rz_group* g, int root) {
         RZG_HIP(g, hipSetDevice(g->device[i]));
         RZG_HIP(g, hipEventRecord(g->evBefore[i], static_cast<hipStream_t>(rz_stream_handle(g->ctx[i]))));
     }
-    // one collective per member, on the stream its render kernel was enqueued on; grouped so that one process
-    // driving several devices cannot deadlock on launch order
-    RZG_NCCL(g, g_rccl.GroupStart());
-    for (size_t i = 0; i < g->ctx.size(); ++i) {
-        const void* send = rz_accum_device_ptr(g->ctx[i]);
-        void* recv = ((int)i == rl) ? g->frame : const_cast<void*>(send);      // recvbuff is only read on the root
-        hipError_t e = hipSetDevice(g->device[i]);
-        ncclResult_t r = e == hipSuccess ? g_rccl.Reduce(send, recv, count, ncclFloat, ncclSum, root, g->comm[i],
-                                                         static_cast<hipStream_t>(rz_stream_handle(g->ctx[i])))
-                                         : ncclUnhandledCudaError;
-        if (r != ncclSuccess) {
-            (void)g_rccl.GroupEnd();
-            return gfail(&g->err, RZ_ERR_HIP, "ncclReduce on rank %d: %s", g->rank[i], g_rccl.GetErrorString(r));
+    if (g->gather) {
+        const int rc = gather_tiles(g, root, rl);
+        if (rc != RZ_OK) return rc;
+    } else {
+        // one collective per member, on the stream its render kernel was enqueued on; grouped so that one process
+        // driving several devices cannot deadlock on launch order
+        RZG_NCCL(g, g_rccl.GroupStart());
+        for (size_t i = 0; i < g->ctx.size(); ++i) {
+            const void* send = rz_accum_device_ptr(g->ctx[i]);
+            void* recv = ((int)i == rl) ? g->frame : const_cast<void*>(send);      // recvbuff is only read on the root
+            hipError_t e = hipSetDevice(g->device[i]);
+            ncclResult_t r = e == hipSuccess ? g_rccl.Reduce(send, recv, count, ncclFloat, ncclSum, root, g->comm[i],
+                                                             static_cast<hipStream_t>(rz_stream_handle(g->ctx[i])))
+                                             : ncclUnhandledCudaError;
+            if (r != ncclSuccess) {
+                (void)g_rccl.GroupEnd();
+                return gfail(&g->err, RZ_ERR_HIP, "ncclReduce on rank %d: %s", g->rank[i], g_rccl.GetErrorString(r));
+            }
         }
+        RZG_NCCL(g, g_rccl.GroupEnd());
     }
-    RZG_NCCL(g, g_rccl.GroupEnd());
     for (size_t i = 0; i < g->ctx.size(); ++i) {
         RZG_HIP(g, hipSetDevice(g->device[i]));
         RZG_HIP(g, hipEventRecord(g->evAfter[i], static_cast<hipStream_t>(rz_stream_handle(g->ctx[i]))));

@@ -165,7 +165,7 @@ private:
 };
 
 // The same frontend glue for N GPUs of one node driven by ONE process: every device holds the whole scene, renders the
-// 8x8-pixel tiles t with t % N == its rank, and one RCCL reduce per frame lands the image on rank 0 (rz_group_*).
+// 8x8-pixel tiles t with t % N == its rank, and one exchange step per frame (a gather of the members' tiles over RCCL) lands the image on rank 0 (rz_group_*).
 // A frontend written against Renderer switches by changing the type.
 class GroupRenderer {
 public:

@@ -76,6 +76,9 @@ def unique_id():
     return bytes(buf)
 
 
+GROUP_LOOPBACK = 0x10000        # RZ_GROUP_LOOPBACK (include/rayzen_hip.h): N rehearsal ranks on the devices named, no communicator
+
+
 class Group:
     """N tile-sharded contexts and their RCCL communicator(s)."""
 
@@ -124,6 +127,11 @@ class Group:
     @property
     def size(self):
         return self._L.rz_group_size(self._g)
+
+    @property
+    def transport(self):
+        """How reduce() moves the frame: 'tile-gather(...)' or 'rccl-reduce' (rz_group_transport)."""
+        return self._L.rz_group_transport(self._g).decode()
 
     @property
     def local_count(self):

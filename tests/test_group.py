@@ -132,3 +132,59 @@ def test_two_contexts_on_two_devices_interleaved():
     g.close()
     assert (frame.view(np.uint32) == ref.view(np.uint32)).all()
     assert root_ms >= 0.0 and max_ms >= root_ms
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks,root,size", [(2, 0, (96, 54)), (3, 2, (100, 45)), (8, 5, (161, 67)), (5, 0, (8, 8))])
+def test_loopback_group_of_n_ranks_gathers_the_single_gpu_frame(nranks, root, size):
+    """The tile gather of an N-rank group, rehearsed on one GPU (RZ_GROUP_LOOPBACK: N members on device 0, device copies in
+    place of ncclSend / ncclRecv): the dealing of tiles, each member's packing, the root's scatter and the stream ordering
+    are the code an N-GPU group runs.  Frame sizes that are no multiple of the 8 x 8 tile, fewer tiles than ranks, a root
+    other than 0, and a second frame continued with sample_base: bit-identical to the oracle and to one context."""
+    from rayzen_amd import scene as S
+    from rayzen_amd.renderer import frame_params
+    from helpers import hip_render, oracle_render
+    sc = S.bunny_scene(n=8, extras=True)
+    (W, H), b = size, 4
+    g = D.Group.create(nranks, devices=[0] * nranks, flags=D.GROUP_LOOPBACK)
+    assert g.size == nranks and g.local_count == nranks and g.transport.startswith("tile-gather(loopback")
+    g.upload_scene(sc)
+    for base, k in ((0, 2), (2, 3)):
+        g.set_frame(frame_params(sc.camera, W, H, len(sc.lights), b, k, base))
+        g.render()
+        g.reduce(root)
+    got = g.read_frame()
+    root_ms, max_ms = g.last_reduce_ms()
+    g.close()
+    ref = oracle_render(sc, W, H, 5, b)
+    assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+    assert (got.view(np.uint32) == hip_render(sc, W, H, 5, b).view(np.uint32)).all()
+    assert root_ms >= 0.0 and max_ms >= root_ms
+
+
+@pytest.mark.gpu
+def test_one_rank_group_with_the_reduce_transport(monkeypatch):
+    """RZ_GROUP_TRANSPORT=reduce: rounds 1-3's ncclReduce(sum) of the whole buffers is still there, same bits."""
+    from rayzen_amd import scene as S
+    from rayzen_amd.renderer import frame_params
+    from helpers import oracle_render
+    monkeypatch.setenv("RZ_GROUP_TRANSPORT", "reduce")
+    sc = S.bunny_scene(n=8, extras=True)
+    W, H, spp, b = 96, 54, 3, 4
+    g = D.Group.create(1)
+    assert g.transport == "rccl-reduce"
+    g.upload_scene(sc)
+    g.set_frame(frame_params(sc.camera, W, H, len(sc.lights), b, spp))
+    g.render(); g.reduce(0)
+    got = g.read_frame()
+    g.close()
+    assert (got.view(np.uint32) == oracle_render(sc, W, H, spp, b).view(np.uint32)).all()
+
+
+def test_loopback_is_refused_where_it_makes_no_sense():
+    L = _lib.hip()
+    import ctypes as C
+    buf = (C.c_char * 128).from_buffer_copy(bytes(128))
+    assert not L.rz_group_create_rank(0, 0, 1, buf, D.GROUP_LOOPBACK)
+    assert b"RZ_GROUP_LOOPBACK" in L.rz_group_last_error(None)
+    assert L.rz_group_transport(None) == b""
