@@ -19,6 +19,8 @@ elif which == "c2g":
 elif which == "ref":        # RayZen's own workload: 800x600, 1 spp, 5 bounces (main.cpp:35-36, 600; FS:675)
     W, H, SPP, B = 800, 600, 1, 5
     sc = S.reference_scene(aspect=W / H)
+elif which in S.NAMED_CONFIGS and which not in ("c2", "c4", "c2g", "ref", "c5"):
+    sc, W, H, SPP, B = S.named_config(which)
 elif which == "c5":
     W, H, SPP, B = 3840, 2160, 16, 8
     sc = S.stress_scene(n=289, aspect=W / H)

@@ -444,6 +444,9 @@ NAMED_CONFIGS = {
     "c5": (lambda: stress_scene(n=289, aspect=16 / 9), 3840, 2160, 32, 8),                   # C5's scene at 32 spp
     "c5full": (lambda: stress_scene(n=289, aspect=16 / 9), 3840, 2160, 128, 8),              # configs[4] as stated
     "ref": (lambda: reference_scene(aspect=800 / 600), 800, 600, 1, 5),                      # RayZen's own workload (main.cpp:35-36, 356-384, 600)
+    # ... RayZen's own scene where a launch has claims to compact: 16 samples per launch at its window size, and a 1080p / 64-spp frame
+    "ref16": (lambda: reference_scene(aspect=800 / 600), 800, 600, 16, 5),
+    "ref64": (lambda: reference_scene(aspect=16 / 9), 1920, 1080, 64, 5),
 }
 
 
