@@ -64,7 +64,7 @@ def measured_fractions(name, kernel_s, wm):
 
 
 def main():
-    which = sys.argv[1:] or ["c1", "ref", "c2close", "c2g", "glassbunny", "c3", "c4", "c4d", "c5", "c5d"]
+    which = sys.argv[1:] or ["c1", "ref", "ref16", "ref64", "c2close", "c2g", "glassbunny", "c3", "c4", "c4d", "c5", "c5d"]
     from rayzen_amd import scene as S
     from rayzen_amd.renderer import Renderer, algorithmic_bytes, frame_params
     from rayzen_amd.workmodel import work_model

@@ -9,7 +9,7 @@ import shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_r04")
 INST = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM")
-for src, dst in (("c2", "c2_kernel"), ("c4", "c4"), ("c5full", "c5"), ("c2g", "c2g"), ("glassbunny", "glassbunny"), ("c2close", "c2close"), ("ref", "ref"), ("c3", "c3")):
+for src, dst in (("c2", "c2_kernel"), ("c4", "c4"), ("c5full", "c5"), ("c2g", "c2g"), ("glassbunny", "glassbunny"), ("c2close", "c2close"), ("ref", "ref"), ("c3", "c3"), ("ref64", "ref64")):
     if not os.path.exists(os.path.join(SRC, f"pmc_{src}.json")):
         continue
     d = os.path.join(ROOT, "profiles", "r04_" + dst)
