@@ -699,7 +699,7 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     // plain persistent loop instead, same image.
     K.wslots = nullptr; K.wslotStride = 0; K.slotFloats = 0; K.nWaitSlots = 0; K.wmeta = nullptr; K.drainEachClaim = 0; K.claimUnits = 0; K.claimScratchFloats = 0;
     K.wpool = nullptr; K.wpoolStride = 0; K.wpoolChunk = 0;
-    if (plan.compact && K.maxBounces < 65536) {
+    if (plan.compact && K.maxBounces < 32768) {     // (a pool entry keeps its path's bounce in 15 bits: rz_kernels.hip, BACK)
         long long chunk = RZ_WPOOL_CHUNK;
         if (const char* e = std::getenv("RZ_WPOOL_CHUNK")) chunk = std::max<long long>(1, std::atoll(e));      // tuning / test aid
         const int nBatches = (K.spp + 63) / 64;
@@ -707,7 +707,10 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
         int nSlots = std::max(2 * groupsPerClaim, 32 / nBatches);
         if (const char* e = std::getenv("RZ_WAIT_SLOTS")) nSlots = std::max(2 * groupsPerClaim, std::atoi(e));  // tuning / test aid
         nSlots = std::min(nSlots, 64);
-        const size_t stride = (size_t)chunk + (size_t)plan.claimUnits * 64 + 64;
+        // a pool's capacity: what a wave may hold when it starts a pass -- fewer than `chunk` paths plus a whole claim's -- and what a
+        // pass can ADD to that: nothing in an opaque scene (a path survives in place or ends); in a transparent one every sample on the
+        // wave's late list (at most RZ_GLATE_CAP, listed in this pass or earlier ones) can be released into the pool behind the survivors
+        const size_t stride = (size_t)chunk + (size_t)plan.claimUnits * 64 + 64 + (c->sceneHasTransparency ? (size_t)RZ_GLATE_CAP : 0);
         // (a group's addends; transparent scenes: + one row, the currentIor each pixel ends with)
         const size_t slotFloats = (size_t)nBatches * 384 + (c->sceneHasTransparency ? 64 : 0);
         const size_t claimScratchFloats = (size_t)groupsPerClaim * slotFloats;

@@ -217,3 +217,23 @@ def test_transparent_claims_tallies_and_the_group_code(seed, monkeypatch):
     monkeypatch.setenv("RZ_GLASS_CLAIMS", "0")
     grp = hip_render(sc, W, H, spp, b)
     assert (grp.view(np.uint32) == ref.view(np.uint32)).all(), mismatch_report(grp, ref)
+
+
+@pytest.mark.parametrize("bounces,pooled", [(32767, True), (32768, False), (70000, False)])
+def test_a_bounce_budget_beyond_the_pool_entrys_field_does_without_the_pool(bounces, pooled, monkeypatch):
+    """A pool entry keeps its path's bounce in 15 bits (rz_kernels.hip: BACK; bit 31 went to the transparent scenes' released
+    samples in round 4).  A launch whose bounce budget does not fit runs the plain persistent loop: same frame.  (Russian
+    roulette ends every path long before: the oracle finishes in a blink.)"""
+    sc, rng = random_scene(4242, opaque=True)
+    W, H, spp = 64, 40, 64
+    sc.camera.aspect = W / H
+    sc.camera.update()
+    monkeypatch.setenv("RZ_GROUPS_PER_CLAIM", "4")
+    from rayzen_amd.renderer import Renderer
+    r = Renderer(0)
+    gpu = hip_render(sc, W, H, spp, bounces, renderer=r)
+    name = r.last_kernel_name()
+    r.close()
+    assert name == ("rz_render_samples+pool" if pooled else "rz_render_samples"), name
+    ref = oracle_render(sc, W, H, spp, bounces, nthreads=16)
+    assert (gpu.view(np.uint32) == ref.view(np.uint32)).all(), mismatch_report(gpu, ref)
