@@ -1,4 +1,5 @@
-"""Multi-GPU: pixel tiles sharded across ranks, one reduce on the accumulation buffer.
+"""Multi-GPU: pixel tiles sharded across ranks, one exchange step on the accumulation buffers (a gather of each rank's own
+tiles -- the C-ABI group's default since round 4, mirrored here by pack_tiles / unpack_tiles / gather_tiles -- or a reduce).
 
 RayZen has no multi-GPU code.  Pixels are independent (fragment_shader.glsl:668-773
 touches only its own gl_FragCoord), so the frame is cut into 8x8-pixel tiles
@@ -37,6 +38,53 @@ def local_tile_count(width, height, rank, nranks):
 def owned_samples(width, height, spp, rank, nranks):
     """Number of camera paths (pixels x spp) rank `rank` renders."""
     return int((owner_map(width, height, nranks) == rank).sum()) * spp
+
+
+def tiles_per_rank(width, height, nranks):
+    """Tiles in one rank's packed set (the same for every rank: the last ranks' sets end in zero tiles)."""
+    tx, ty = tile_grid(width, height)
+    return (tx * ty + nranks - 1) // nranks
+
+
+def pack_tiles(accum, rank, nranks):
+    """The host mirror of rz_pack_tiles (rayzen_amd/csrc/hip/rz_group.hip): rank `rank`'s own tiles of the (H, W, 4) buffer in the
+    order of its local tiles (local tile lt is tile lt * nranks + rank), 64 pixels each, pixel l of a tile at (l & 7, l >> 3);
+    pixels beyond the frame's edge and tiles beyond the last one are zeros.  -> (tiles_per_rank, 64, 4) float32."""
+    h, w = accum.shape[:2]
+    tx, ty = tile_grid(w, h)
+    padded = np.zeros((ty * TILE_H, tx * TILE_W, 4), np.float32)
+    padded[:h, :w] = accum
+    tiles = padded.reshape(ty, TILE_H, tx, TILE_W, 4).transpose(0, 2, 1, 3, 4).reshape(tx * ty, TILE_H * TILE_W, 4)
+    out = np.zeros((tiles_per_rank(w, h, nranks), TILE_H * TILE_W, 4), np.float32)
+    mine = tiles[rank::nranks]
+    out[:mine.shape[0]] = mine
+    return out
+
+
+def unpack_tiles(sets, width, height):
+    """The host mirror of rz_unpack_tiles: the frame from the ranks' packed sets, (nranks, tiles_per_rank, 64, 4) -> (H, W, 4)."""
+    nranks = sets.shape[0]
+    tx, ty = tile_grid(width, height)
+    tiles = np.zeros((tx * ty, TILE_H * TILE_W, 4), np.float32)
+    for r in range(nranks):
+        n = len(range(r, tx * ty, nranks))
+        tiles[r::nranks] = sets[r][:n]
+    padded = tiles.reshape(ty, tx, TILE_H, TILE_W, 4).transpose(0, 2, 1, 3, 4).reshape(ty * TILE_H, tx * TILE_W, 4)
+    return np.ascontiguousarray(padded[:height, :width])
+
+
+def gather_tiles(accum, rank, nranks, dst=0, group=None):
+    """The group's exchange step over torch.distributed (the CPU rehearsal of rz_group_reduce's default transport): every rank
+    packs its own tiles, rank `dst` gathers the sets and scatters them into the frame.  Returns the frame on `dst`, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    mine = torch.from_numpy(pack_tiles(accum, rank, nranks))
+    if rank == dst:
+        sets = [torch.empty_like(mine) for _ in range(nranks)]
+        dist.gather(mine, gather_list=sets, dst=dst, group=group)
+        return unpack_tiles(np.stack([s.numpy() for s in sets]), accum.shape[1], accum.shape[0])
+    dist.gather(mine, gather_list=None, dst=dst, group=group)
+    return None
 
 
 def reduce_accum(tensor, dst=0, group=None):

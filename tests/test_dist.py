@@ -174,3 +174,63 @@ def test_bench_with_gpus_2_and_no_launcher_reaches_the_one_process_group(monkeyp
     with pytest.raises(SystemExit) as e:
         b.main(["--gpus", "2", "--no-cpu-baseline"])
     assert "only 1 HIP device" in str(e.value)
+
+
+# ---- the tile gather (round 4: rz_group_reduce's default transport), rehearsed on the CPU -------------------------------
+
+@pytest.mark.parametrize("size,nranks", [((72, 40), 2), ((100, 45), 3), ((161, 67), 8), ((8, 8), 5)])
+def test_pack_and_unpack_tiles_round_trip(size, nranks):
+    """Every pixel of the frame comes back from its owner's packed set; a rank's set holds exactly its own tiles."""
+    W, H = size
+    rng = np.random.default_rng(7)
+    frame = rng.random((H, W, 4), dtype=np.float32)
+    own = D.owner_map(W, H, nranks)
+    sets = []
+    for r in range(nranks):
+        mine = np.where((own == r)[..., None], frame, np.float32(0))     # what rank r's accumulation buffer holds
+        s = D.pack_tiles(mine, r, nranks)
+        assert s.shape == (D.tiles_per_rank(W, H, nranks), 64, 4)
+        assert np.count_nonzero(s) == np.count_nonzero(mine)
+        sets.append(s)
+    got = D.unpack_tiles(np.stack(sets), W, H)
+    assert (got.view(np.uint32) == frame.view(np.uint32)).all()
+
+
+def _gather_worker(rank, world, port, W, H, spp, bounces, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from oracle import rzo
+    from rayzen_amd import scene as S
+    from helpers import oracle_frame, oracle_scene
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = S.cornell_scene()
+    osc, fr = oracle_scene(sc), oracle_frame(sc, W, H, spp, bounces)
+    tx, ty = D.tile_grid(W, H)
+    acc = np.zeros((H, W, 4), np.float32)
+    for t in range(rank, tx * ty, world):
+        x0, y0 = (t % tx) * 8, (t // tx) * 8
+        rzo.render(osc, fr, accum=acc, crop=(x0, y0, min(x0 + 8, W), min(y0 + 8, H)), nthreads=1)
+    frame = D.gather_tiles(acc, rank, world, dst=1)          # (a root other than 0)
+    if rank == 1:
+        np.save(out_path, frame)
+    else:
+        assert frame is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_sharded_render_plus_tile_gather_is_bit_identical_to_single_rank(tmp_path):
+    """world_size 2 over gloo: each rank renders its own tiles (the oracle stands in for the GPU), packs them, rank 1 gathers and
+    scatters -- the data flow of rz_group_reduce's default transport -- and holds the single-rank frame bit for bit."""
+    import torch.multiprocessing as mp
+    from helpers import oracle_render
+    from rayzen_amd import scene as S
+    W, H, spp, bounces = 75, 41, 2, 3
+    out = str(tmp_path / "gathered.npy")
+    mp.spawn(_gather_worker, args=(2, _free_port(), W, H, spp, bounces, out), nprocs=2, join=True)
+    got = np.load(out)
+    want = oracle_render(S.cornell_scene(), W, H, spp, bounces, nthreads=2)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
