@@ -138,31 +138,40 @@ def main(argv=None):
     from rayzen_amd import scene as S
     from rayzen_amd.renderer import Renderer, algorithmic_bytes, frame_params
 
-    ndev = rzlib.hip().rz_device_count()
-    if ndev <= 0:
-        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     if mode == "local-group" and a.reduce != "group":
         raise SystemExit("--reduce torch / torch-gloo need one process per GPU: start bench.py with torch.distributed.run")
     if a.loopback and mode != "local-group":
         raise SystemExit("--loopback rehearses `--gpus N` (N > 1) started as one plain process")
-    if mode == "local-group" and ndev < world and not a.loopback:
-        raise SystemExit(f"--gpus {world} but only {ndev} HIP device(s) are visible to this process")
 
     torch = dist = dev = None
     use_group = world > 1 and a.reduce == "group"
     use_nccl = mode == "ranks" and a.reduce in ("group", "torch")
     dev_index = 0
     if mode == "ranks":
+        # torch FIRST, and on its device, before librayzen_hip.so is loaded: the torch wheel bundles its own HIP runtime
+        # (torch/lib/libamdhip64.so), and a process that has /opt/rocm's mapped already -- which loading the library first would
+        # do -- leaves torch with "No HIP GPUs are available" (profiles/scripts/hip_runtime_order.py; found in round 4: the
+        # launcher mode had not run on a GPU box since the device count below moved in front of this block).  Loaded second,
+        # the library binds to the runtime torch brought -- one runtime in the process, and one RCCL (rz_group.hip).
         import torch
         import torch.distributed as dist
+        if torch.cuda.device_count() <= 0:
+            raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
         dev_index = local_rank if use_nccl else local_rank % torch.cuda.device_count()
         torch.cuda.set_device(dev_index)
         dev = torch.device("cuda", dev_index)
+        torch.zeros(1, device=dev)      # (the runtime is up before anything else asks for it)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if use_nccl:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # group mode: barrier + max-over-ranks only
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    ndev = rzlib.hip().rz_device_count()
+    if ndev <= 0:
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if mode == "local-group" and ndev < world and not a.loopback:
+        raise SystemExit(f"--gpus {world} but only {ndev} HIP device(s) are visible to this process")
 
     W, H, bounces = a.width, a.height, a.bounces
     spp_total = a.spp_total if a.spp_total > 0 else a.spp * world   # every rank renders ALL samples of its own pixels

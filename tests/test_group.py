@@ -188,3 +188,46 @@ def test_loopback_is_refused_where_it_makes_no_sense():
     assert not L.rz_group_create_rank(0, 0, 1, buf, D.GROUP_LOOPBACK)
     assert b"RZ_GROUP_LOOPBACK" in L.rz_group_last_error(None)
     assert L.rz_group_transport(None) == b""
+
+
+@pytest.mark.gpu
+def test_group_beside_torch_distributed_in_one_process(tmp_path):
+    """What bench.py's launcher mode does, for one rank: torch FIRST (its wheel bundles a HIP runtime and an RCCL of its own;
+    a process that loads librayzen_hip.so before torch leaves torch without a GPU -- profiles/scripts/hip_runtime_order.py), an
+    `nccl` process group, THEN the library, which must bind to the runtime and the RCCL already in the process, form its own
+    communicator from an id broadcast over torch's, render, land the frame, and agree with the oracle.  In a child process:
+    this one has the library loaded already."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "beside_torch.py"
+    script.write_text(f'''
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+import numpy as np
+from rayzen_amd import dist as D, scene as S
+from rayzen_amd.renderer import frame_params
+from helpers import oracle_render
+uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+uid.copy_(torch.frombuffer(bytearray(D.unique_id()), dtype=torch.uint8))
+dist.broadcast(uid, src=0)
+g = D.Group.create_rank(0, 0, 1, bytes(uid.cpu().numpy().tobytes()))
+sc = S.bunny_scene(n=8, extras=True)
+W, H, spp, b = 96, 54, 3, 4
+g.upload_scene(sc); g.set_frame(frame_params(sc.camera, W, H, len(sc.lights), b, spp))
+g.render(); g.reduce(0); dist.barrier(); g.sync()
+got = g.read_frame(); g.close()
+maps = sorted({{l.split()[-1] for l in open("/proc/self/maps") if "amdhip" in l or "librccl" in l}})
+assert len([m for m in maps if "amdhip" in m]) == 1 and len([m for m in maps if "librccl" in m]) == 1, maps
+assert (got.view(np.uint32) == oracle_render(sc, W, H, spp, b).view(np.uint32)).all()
+dist.destroy_process_group()
+print("OK one HIP runtime, one RCCL:", maps)
+''')
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK one HIP runtime" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
