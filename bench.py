@@ -472,6 +472,30 @@ def main(argv=None):
             out["cpu_baseline"]["full_frame"] = {"value": round(W * H * a.spp / tf / 1e6, 4), "seconds": round(tf, 2),
                                                  "bit_identical_to_gpu": bool((full.view(np.uint32) == gpu.view(np.uint32)).all())}
         out["parity"] = {"linf_vs_oracle_on_sample": err, "bit_identical_pixels": same, "pixels_compared": tot}
+    if rank == 0 and world > 1 and not a.no_cpu_baseline:
+        # N > 1: no CPU baseline (that is the N = 1 line's), but the PARITY leg stays -- a few bands of the frame the group has
+        # landed on rank 0, against the oracle at the frame's full sample count: tiles that arrived in the wrong place would
+        # pass frame_check (every pixel has the same sample count) and fail here
+        from oracle import rzo
+        from helpers import oracle_frame, oracle_scene
+        ncores = a.cpu_threads if a.cpu_threads > 0 else min(16, len(os.sched_getaffinity(0)))
+        osc = oracle_scene(sc)
+        ofr = oracle_frame(sc, W, H, spp_total, bounces)
+        ref = np.zeros((H, W, 4), np.float32)
+        nb = max(1, min(a.cpu_bands, 8))
+        bands, same, tot, err = [], 0, 0, 0.0
+        for b in range(nb):
+            y0 = min(H - 8, int((b + 0.5) * H / nb) // 8 * 8)
+            if y0 in bands:
+                continue
+            rzo.render(osc, ofr, accum=ref, crop=(0, y0, W, y0 + 8), nthreads=ncores)
+            bands.append(y0)
+            g, o = final[y0:y0 + 8], ref[y0:y0 + 8]
+            err = max(err, float(np.abs(g.astype(np.float64) - o.astype(np.float64)).max()))
+            same += int((g.view(np.uint32) == o.view(np.uint32)).all(axis=-1).sum())
+            tot += g.shape[0] * g.shape[1]
+        out["parity"] = {"linf_vs_oracle_on_sample": err, "bit_identical_pixels": same, "pixels_compared": tot,
+                         "sample": f"{len(bands)} full-width 8-row bands of the landed {W}x{H}x{spp_total}spp frame (every band crosses the tiles of all {world} ranks)"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if group is not None:
