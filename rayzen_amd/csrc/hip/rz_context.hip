@@ -118,7 +118,7 @@ struct rz_ctx {
     // device re-layout (rz_relayout.hip): the caller's raw arrays on the device, the fill of dPairs / dTris, scratch
     DevBuf dRawNodes, dRawIdx, dRawTris, dRelayoutWs, dClaimScratch;
     DevBuf dSnap;                                  // transparent scenes: the resident waves' sample prefixes (rz_path.h: snapshot_store)
-    DevBuf dWavePools, dDeferAdd, dDeferFlags;     // the resident waves' pools of parked paths and the bookkeeping of their wait slots (rz_kernels.hip: pool_process; the slots themselves: dClaimScratch; dDeferAdd: unused since round 4)
+    DevBuf dWavePools, dWaitMeta;     // the resident waves' pools of parked paths and the bookkeeping of their wait slots (rz_kernels.hip: pool_process; the slots themselves: behind the claim scratch in dClaimScratch)
     size_t lastScratchBytes = 0;                   // what the last compacting launch's waves had in scratch (pools + wait slots + bookkeeping)
     int* relayoutPinned = nullptr;
     bool layoutOnDevice = false;        // dPairs / dTris were produced on the device (hPairs / hTris are empty)
@@ -691,10 +691,10 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     // Compacting launches: every resident wave's scratch (rz_kernels.hip: WAIT SLOTS, pool_process) --
     //   * its pool of parked paths: room for the chunk it collects before it traces them + the most one more claim can park;
     //   * its claim scratch (the addends of the claim it is running, 1.5 KB per unit) and behind it its wait slots, one waiting
-    //     group's addends (batches x 1.5 KB) each: at least twice the groups of a claim, 32 / batches by default (a claim that
+    //     group's addends (batches x 1.5 KB) each: twice the groups of a claim by default (a claim that
     //     finds fewer free ones than it has groups makes the wave trace its pool first; RZ_WAIT_SLOTS overrides);
     //   * 2 ints of bookkeeping per slot.
-    // C2: 83 + 12 + 48 KB per wave, 0.59 GB for the grid (round 3: 3.7 GB, of which 3.2 GB an array of 1.5 KB per unit of the launch).
+    // C2: 80 + 12 + 24 KB per wave, 470 MiB for the grid (round 3: 3.7 GB, of which 3.2 GB an array of 1.5 KB per unit of the launch).
     // The scratch is optional: a launch that cannot have it (or is told so: RZ_DEBUG_NO_POOL_MEMORY=1, a test aid) runs the
     // plain persistent loop instead, same image.
     K.wslots = nullptr; K.wslotStride = 0; K.slotFloats = 0; K.nWaitSlots = 0; K.wmeta = nullptr; K.drainEachClaim = 0; K.claimUnits = 0; K.claimScratchFloats = 0;
@@ -704,7 +704,9 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
         if (const char* e = std::getenv("RZ_WPOOL_CHUNK")) chunk = std::max<long long>(1, std::atoll(e));      // tuning / test aid
         const int nBatches = (K.spp + 63) / 64;
         const int groupsPerClaim = std::max(1, plan.perClaim);
-        int nSlots = std::max(2 * groupsPerClaim, 32 / nBatches);
+        // (twice a claim's groups: measured on the final build against 24 and 32 slots, C2 / C3 / C4 / C5 / glass all within
+        //  0.4 % -- profiles/r04_wait_slots/slots_chunk_final.log -- and 24 KB per wave less to keep: C2's scratch 553 -> 470 MiB)
+        int nSlots = std::max(2 * groupsPerClaim, 16 / nBatches);
         if (const char* e = std::getenv("RZ_WAIT_SLOTS")) nSlots = std::max(2 * groupsPerClaim, std::atoi(e));  // tuning / test aid
         nSlots = std::min(nSlots, 64);
         // a pool's capacity: what a wave may hold when it starts a pass -- fewer than `chunk` paths plus a whole claim's -- and what a
@@ -722,7 +724,7 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
         if (nSlots >= groupsPerClaim && !(forceNo && std::atoi(forceNo) != 0) && (!c->sceneHasTransparency || snapOn) &&
             ensure_optional(c->dWavePools, (size_t)plan.grid * stride * RZ_GPOOL_FIELDS * sizeof(unsigned)) &&
             ensure_optional(c->dClaimScratch, (size_t)plan.grid * (claimScratchFloats + nSlots * slotFloats + slotPad) * sizeof(float)) &&
-            ensure_optional(c->dDeferFlags, (size_t)plan.grid * 4 * nSlots * sizeof(int32_t))) {
+            ensure_optional(c->dWaitMeta, (size_t)plan.grid * 4 * nSlots * sizeof(int32_t))) {
             K.wpool = static_cast<unsigned*>(c->dWavePools.p);
             K.wpoolStride = (uint32_t)stride;
             K.wpoolChunk = (uint32_t)chunk;
@@ -734,7 +736,7 @@ int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
             if (const char* e = std::getenv("RZ_GLASS_BOX_HINT")) K.glassBoxHint = std::atoi(e) != 0 ? 1 : 0;      // A/B and test aid
             K.slotFloats = (uint32_t)slotFloats;
             K.nWaitSlots = nSlots;
-            K.wmeta = static_cast<int32_t*>(c->dDeferFlags.p);
+            K.wmeta = static_cast<int32_t*>(c->dWaitMeta.p);
             K.drainEachClaim = plan.drainEachClaim ? 1 : 0;
         }
     }
@@ -952,7 +954,7 @@ void rz_destroy(rz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
-                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs, &c->dTlasDfs, &c->dTriN, &c->dRawNodes, &c->dRawIdx, &c->dRawTris, &c->dRelayoutWs, &c->dClaimScratch, &c->dWavePools, &c->dDeferAdd, &c->dDeferFlags, &c->dSnap})
+                      &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs, &c->dTlasDfs, &c->dTriN, &c->dRawNodes, &c->dRawIdx, &c->dRawTris, &c->dRelayoutWs, &c->dClaimScratch, &c->dWavePools, &c->dWaitMeta, &c->dSnap})
         b->release();
     if (c->tlasHostCounts) (void)hipHostFree(c->tlasHostCounts);
     if (c->relayoutPinned) (void)hipHostFree(c->relayoutPinned);

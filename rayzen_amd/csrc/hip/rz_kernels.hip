@@ -575,8 +575,8 @@ struct ClaimMap {
 //     in the pool pass in which its last path comes back, not at the end of the launch;
 //   * a claim may start only when as many slots are free as it has groups: otherwise the wave traces its pool first (every pass
 //     ends paths; an empty pool means that every slot is free).
-// Scratch per resident wave on C2: pool 83 KB + claim scratch 12 KB + 32 slots x 1.5 KB = 143 KB, 0.59 GB for the grid, where
-// round 3 took 3.7 GB; C5: 0.9 GB where it took 25.
+// Scratch per resident wave on C2: pool 80 KB + claim scratch 12 KB + 16 slots x 1.5 KB = 116 KB + the meta block, 470 MiB for
+// the grid of 4 096 waves where round 3 took 3.7 GB; C5: 814 MiB where it took 25 GB (rz_debug_last_plan().scratch_mib).
 // The meta block of a wave (ints): [0, NS) the launch-order index of the group in the slot | [NS, 2 NS) its outstanding paths
 // (-1: the slot is free).  Paths that end decrement with atomics that return nothing; the wave LOOKS at the counts once per pool
 // pass and once per claim that has groups to park -- lane s loads slot s's count past the L1 (the atomics act on the L2), a
