@@ -33,6 +33,9 @@
 
 namespace rz {
 
+#ifndef RZ_ASM_WALK
+#define RZ_ASM_WALK 1
+#endif
 #ifndef RZ_DESCEND_MIN_LANES
 #define RZ_DESCEND_MIN_LANES 4   // leave the descend loop when fewer lanes than this still have an internal node (lane=sample kernel on C2: 1 -> 17.6 ms, 2 -> 17.4, 3..6 -> 17.15-17.2, 8 -> 17.3, 12 -> 17.4)
 #endif
@@ -362,6 +365,104 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
                     // pixel nearly always do -- the walk stays on the scalar unit: the cursor is an SGPR, the decision two ballots
                     // and a compare, and none of the per-lane selects, exec masks and the uniformity test of the general step are
                     // executed (they were half of a step's 61 instructions).  Same pushes, same culls, same order per lane.
+#if RZ_ASM_WALK && !defined(RZ_PROF)
+                    if constexpr (!COUNT && !OVF && OCT >= 0) {
+                        // The same loop, hand-written.  hipcc keeps the loop's wave-uniform flags as 64-bit lane
+                        // masks and spends 19 scalar and branch instructions per step beside the 21 vector ones; this body spends 11:
+                        // shift, fetch, wait | the two slab tests in their octant form | mR, "everybody right?" -> (a left child to
+                        // stack?) cursor, loop | else "nobody right, everybody left?" -> cursor, loop | else out.  Same fetches,
+                        // same arithmetic on the same operands, same pushes per lane, same culls against the lane's own tLoc.
+                        // Fixed registers (the instruction set has no way to name half of an operand): s[80:95] the pair,
+                        // v[6:17] the six packed plane products, v[18:19] the stack entry (left child, its entry distance), v20-v25.
+                        int u = ucur, lenc, renc, mixedI, off;
+                        const unsigned long long ex = rz_ballot(true);
+                        unsigned long long mHl, mHr, mRr, sv;
+                        float tl, tr;
+                        const f32x2 ox2 = {lo.x, lo.x}, oy2 = {lo.y, lo.y}, oz2 = {lo.z, lo.z};
+                        const f32x2 ix2 = {inv.x, inv.x}, iy2 = {inv.y, inv.y}, iz2 = {inv.z, inv.z};
+                        const unsigned ldsCol = (unsigned)(unsigned long long)bstk.lds;      // (a flat LDS address: its low half is the LDS offset)
+#define RZ_WALK_ASM(NLX, FLX, NLY, FLY, NLZ, FLZ, NRX, FRX, NRY, FRY, NRZ, FRZ)                                                        \
+                        asm volatile(                                                                                                  \
+                            "1:\n\t"                                                                                                   \
+                            "s_lshl_b32 %[off], %[u], 6\n\t"                                                                           \
+                            "s_load_dwordx16 s[80:95], %[base], %[off]\n\t"                                                            \
+                            "s_waitcnt lgkmcnt(0)\n\t"                                                                                 \
+                            "v_pk_add_f32 v[6:7], s[80:81], %[ox] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                       \
+                            "v_pk_add_f32 v[8:9], s[82:83], %[oy] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                       \
+                            "v_pk_add_f32 v[10:11], s[84:85], %[oz] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                     \
+                            "v_pk_mul_f32 v[6:7], %[ix], v[6:7]\n\t"                                                                   \
+                            "v_pk_mul_f32 v[8:9], %[iy], v[8:9]\n\t"                                                                   \
+                            "v_pk_mul_f32 v[10:11], %[iz], v[10:11]\n\t"                                                               \
+                            "v_pk_add_f32 v[12:13], s[86:87], %[ox] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                     \
+                            "v_pk_add_f32 v[14:15], s[88:89], %[oy] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                     \
+                            "v_pk_add_f32 v[16:17], s[90:91], %[oz] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                     \
+                            "v_max3_f32 v19, " NLX ", " NLY ", " NLZ "\n\t"                                                            \
+                            "v_pk_mul_f32 v[12:13], %[ix], v[12:13]\n\t"                                                               \
+                            "v_pk_mul_f32 v[14:15], %[iy], v[14:15]\n\t"                                                               \
+                            "v_pk_mul_f32 v[16:17], %[iz], v[16:17]\n\t"                                                               \
+                            "v_min3_f32 v20, " FLX ", " FLY ", " FLZ "\n\t"                                                            \
+                            "v_max_f32_e32 v21, 0, v19\n\t"                                                                            \
+                            "v_cmp_ge_f32_e64 %[mhl], v20, v21\n\t"                                                                    \
+                            "v_max3_f32 v22, " NRX ", " NRY ", " NRZ "\n\t"                                                            \
+                            "v_min3_f32 v23, " FRX ", " FRY ", " FRZ "\n\t"                                                            \
+                            "v_max_f32_e32 v24, 0, v22\n\t"                                                                            \
+                            "v_cmp_ge_f32_e64 %[mhr], v23, v24\n\t"                                                                    \
+                            "v_cmp_gt_f32_e32 vcc, v22, %[tloc]\n\t"                                                                   \
+                            "s_andn2_b64 %[mr], %[mhr], vcc\n\t"                                                                       \
+                            "s_cmp_eq_u64 %[mr], %[ex]\n\t"                                                                            \
+                            "s_cbranch_scc0 3f\n\t"                                                                                    \
+                            "s_cmp_eq_u64 %[mhl], 0\n\t"                                                                               \
+                            "s_cbranch_scc1 2f\n\t"                                                                                    \
+                            "s_and_saveexec_b64 %[sv], %[mhl]\n\t"                                                                     \
+                            "v_lshl_add_u32 v25, %[sp], 9, %[lds]\n\t"                                                                 \
+                            "v_add_u32_e32 %[sp], 1, %[sp]\n\t"                                                                        \
+                            "v_mov_b32_e32 v18, s92\n\t"                                                                               \
+                            "ds_write_b64 v25, v[18:19]\n\t"                                                                           \
+                            "s_mov_b64 exec, %[sv]\n"                                                                                  \
+                            "2:\n\t"                                                                                                   \
+                            "s_mov_b32 %[u], s93\n\t"                                                                                  \
+                            "s_cmp_gt_i32 s93, -1\n\t"                                                                                 \
+                            "s_cbranch_scc1 1b\n\t"                                                                                    \
+                            "s_mov_b32 %[mixed], 0\n\t"                                                                                \
+                            "s_branch 9f\n"                                                                                            \
+                            "3:\n\t"                                                                                                   \
+                            "s_mov_b32 %[mixed], 1\n\t"                                                                                \
+                            "s_cmp_lg_u64 %[mr], 0\n\t"                                                                                \
+                            "s_cbranch_scc1 9f\n\t"                                                                                    \
+                            "v_cmp_gt_f32_e32 vcc, v19, %[tloc]\n\t"                                                                   \
+                            "s_andn2_b64 %[mr], %[mhl], vcc\n\t"                                                                       \
+                            "s_cmp_eq_u64 %[mr], %[ex]\n\t"                                                                            \
+                            "s_cbranch_scc0 9f\n\t"                                                                                    \
+                            "s_mov_b32 %[u], s92\n\t"                                                                                  \
+                            "s_cmp_gt_i32 s92, -1\n\t"                                                                                 \
+                            "s_cbranch_scc1 1b\n\t"                                                                                    \
+                            "s_mov_b32 %[mixed], 0\n"                                                                                  \
+                            "9:\n\t"                                                                                                   \
+                            "v_mov_b32_e32 %[tl], v19\n\t"                                                                             \
+                            "v_mov_b32_e32 %[tr], v22\n\t"                                                                             \
+                            "s_mov_b32 %[lenc], s92\n\t"                                                                               \
+                            "s_mov_b32 %[renc], s93"                                                                                   \
+                            : [u] "+s"(u), [sp] "+v"(sp), [off] "=&s"(off), [mhl] "=&s"(mHl), [mhr] "=&s"(mHr), [mr] "=&s"(mRr),         \
+                              [sv] "=&s"(sv), [mixed] "=&s"(mixedI), [tl] "=&v"(tl), [tr] "=&v"(tr), [lenc] "=&s"(lenc), [renc] "=&s"(renc) \
+                            : [base] "s"(pairs), [ox] "v"(ox2), [oy] "v"(oy2), [oz] "v"(oz2), [ix] "v"(ix2), [iy] "v"(iy2), [iz] "v"(iz2), \
+                              [tloc] "v"(tLoc), [ex] "s"(ex), [lds] "v"(ldsCol)                                                         \
+                            : "memory", "vcc", "scc", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", \
+                              "s92", "s93", "s94", "s95", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", \
+                              "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25")
+                        if constexpr (OCT == 0) { RZ_WALK_ASM("v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17"); }
+                        else if constexpr (OCT == 1) { RZ_WALK_ASM("v7", "v6", "v8", "v9", "v10", "v11", "v13", "v12", "v14", "v15", "v16", "v17"); }
+                        else if constexpr (OCT == 2) { RZ_WALK_ASM("v6", "v7", "v9", "v8", "v10", "v11", "v12", "v13", "v15", "v14", "v16", "v17"); }
+                        else if constexpr (OCT == 3) { RZ_WALK_ASM("v7", "v6", "v9", "v8", "v10", "v11", "v13", "v12", "v15", "v14", "v16", "v17"); }
+                        else if constexpr (OCT == 4) { RZ_WALK_ASM("v6", "v7", "v8", "v9", "v11", "v10", "v12", "v13", "v14", "v15", "v17", "v16"); }
+                        else if constexpr (OCT == 5) { RZ_WALK_ASM("v7", "v6", "v8", "v9", "v11", "v10", "v13", "v12", "v14", "v15", "v17", "v16"); }
+                        else if constexpr (OCT == 6) { RZ_WALK_ASM("v6", "v7", "v9", "v8", "v11", "v10", "v12", "v13", "v15", "v14", "v17", "v16"); }
+                        else if constexpr (OCT == 7) { RZ_WALK_ASM("v7", "v6", "v9", "v8", "v11", "v10", "v13", "v12", "v15", "v14", "v17", "v16"); }
+#undef RZ_WALK_ASM
+                        if (mixedI != 0) step(in_mask(mHl), tl, in_mask(mHr), tr, lenc, renc);      // the lanes part ways here: the general step, on the pair just tested
+                        else cur = u;
+                    } else
+#endif
+                    {
                     int u = ucur, lenc, renc;
                     const unsigned long long ex = rz_ballot(true);
                     float tl, tr;
@@ -391,6 +492,7 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
                     } while (!mixed && u >= 0);
                     if (mixed) step(hl, tl, hr, tr, lenc, renc);    // the lanes part ways here: the general step, on the pair just tested
                     else cur = u;
+                    }
                 } else
 #endif
                 {
