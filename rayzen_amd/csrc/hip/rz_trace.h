@@ -33,6 +33,9 @@
 
 namespace rz {
 
+#ifndef RZ_UNIFORM_LEAF
+#define RZ_UNIFORM_LEAF 1
+#endif
 #ifndef RZ_ASM_WALK
 #define RZ_ASM_WALK 1
 #endif
@@ -528,6 +531,33 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
             int i = 0;
             unsigned long long triMask = rz_ballot(0 < count);
             bool any = triMask != 0ull;
+#if RZ_UNIFORM_LEAF
+            // Every lane that has triangles to test stands at the SAME leaf (the samples of a pixel mostly do: they walked there
+            // together): its triangles come through the scalar cache, 48 B once per wave instead of three 16-B loads per lane,
+            // and the test takes them from scalar registers.  The same tests in the same order on the same values.
+            if constexpr (!MI) {
+                if (any) {
+                    const int ucur = __builtin_amdgcn_readlane(cur, (int)__builtin_ctzll(triMask));
+                    if (rz_ballot(0 < count && cur != ucur) == 0ull) {
+                        const int uv = ~ucur, ufirst = uv >> 4, ucount = uv & 15;
+                        if (in_mask(triMask)) {
+                            for (int k = 0; k < ucount; ++k) {
+                                RZ_SITE(c, 2);
+                                const float* __restrict__ tf = reinterpret_cast<const float*>(tris + ufirst + k);
+                                const f32x8 a = sload8(tf);
+                                const f32x4s b = sload4(tf + 8);
+                                float t;
+                                bool pastU;
+                                const bool hit = moller_trumbore(lo, ld, mk3(a[0], a[1], a[2]), mk3(a[3], a[4], a[5]), mk3(a[6], a[7], b[0]), t, pastU);
+                                if (COUNT && pastU) c.triangles_past_u += 1;
+                                if (hit && t < tLoc) { tLoc = t; best = ufirst + k; }
+                            }
+                        }
+                        any = false;
+                    }
+                }
+            }
+#endif
             while (any) {
                 if (in_mask(triMask)) {
                     RZ_SITE(c, 2);
