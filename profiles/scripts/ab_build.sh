@@ -17,5 +17,5 @@ fi
 STAMP=$(cd "$ROOT" && python3 -c "import sys; from rayzen_amd import build; print(build.source_hash(tuple(sys.argv[1:])))" "$@")
 [ "$REV" = WORK ] || STAMP=$(printf '%064d' 0)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -greedy-regclass-priority-trumps-globalness "$@" "-DRZ_SOURCE_HASH=\"$STAMP\"" -I "$INC" -I "$H" \
-    -shared -o "$ROOT/rayzen_amd/lib/librayzen_hip_$NAME.so" "$H"/*.hip 2>/dev/null
+    -shared -o "$ROOT/rayzen_amd/lib/librayzen_hip_$NAME.so" "$H"/*.hip -ldl 2> "$ROOT/gpurun_out/ab_build_$NAME.err" || { grep -m5 "error" "$ROOT/gpurun_out/ab_build_$NAME.err"; echo "BUILD FAILED: librayzen_hip_$NAME.so"; exit 1; }
 echo "built librayzen_hip_$NAME.so from $REV $*"
