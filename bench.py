@@ -6,9 +6,10 @@
 
 One "step" = one pass of the hot path over one frame of synthetic input: BASELINE.json configs[1], the
 ~69k-triangle "bunny" scene (procedural stand-in, see rayzen_amd/scene.py) at 1920x1080, 4 bounces, 64 samples per
-pixel per GPU.  At N > 1 the frame's 8x8-pixel tiles are dealt round-robin to the ranks and ONE exchange step (a gather of the ranks' own tiles over RCCL; RZ_GROUP_TRANSPORT=reduce: a reduce(SUM)) per
-step lands the frame on rank 0 -- both through the C-ABI's multi-GPU group (include/rayzen_hip.h: rz_group_*), the
-reduce enqueued on each member's render stream.  Two ways to start it:
+pixel per GPU.  At N > 1 the frame's 8x8-pixel tiles are dealt round-robin to the ranks and ONE exchange step per step
+lands the frame on rank 0: one RCCL reduce(SUM) of the accumulation buffers (`--transport reduce`, the default: what
+BASELINE.json's north_star names) or a gather of the ranks' own tiles (`--transport gather`) -- both through the C-ABI's
+multi-GPU group (include/rayzen_hip.h: rz_group_*), enqueued on each member's render stream.  Two ways to start it:
   * `python bench.py --gpus N` as ONE plain process (no launcher, WORLD_SIZE unset): rz_group_create(N) -- N contexts on
     the node's first N devices and their communicators from ncclCommInitAll; nothing is re-executed, no torch.distributed;
   * under torch.distributed.run (WORLD_SIZE = N): one process per GPU, rz_group_create_rank with an id broadcast over
@@ -16,7 +17,12 @@ reduce enqueued on each member's render stream.  Two ways to start it:
 The JSON says which ran (`config.parallelism`), how many ranks RCCL saw (`rccl_ranks`) and what the reduce cost
 (`reduce_ms`: HIP events around it on the root's stream).  Default N > 1 workload: every rank renders 64*N spp of its own
 pixels (per-GPU work constant: "weak"); `--spp-total T` fixes the frame at T spp instead ("strong"; `--spp-total 256` at
-N = 8 is BASELINE configs[2], the C3 line).
+N = 8 is BASELINE configs[2], the C3 line).  Every N > 1 line ALSO carries `configs2`: three extra steps of the 256-spp frame
+of BASELINE configs[2] on the same N GPUs (strong scaling of that frame; at N = 8 it IS configs[2]).
+A run cannot die on the exchange step: a group whose RCCL communicator cannot be made, or whose first exchange fails in the
+warm-up, is rebuilt in the same process (never re-executed) on the next transport down -- rccl gather -> rccl reduce -> plain
+device copies between the members' GPUs (one-process mode) / torch.distributed.reduce (launcher mode) -- and the line says
+which ran and why (`transport`, `transport_fallback`).
 Scene buffers are resident in HBM before the timed region; nothing is skipped inside it.
 
 Rank 0 prints ONE JSON line.  `value` = total camera paths (pixels x spp) / wall time of the K timed steps (max over
@@ -31,6 +37,10 @@ import os
 import sys
 import time
 
+# RCCL / cross-process device memory on this pool need dmabuf IPC (the host driver supports nothing else); exported on
+# the boxes already -- set here too, before any HIP runtime is loaded, for whoever starts the bench from a bare environment
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -40,7 +50,7 @@ SIMDS = 256 * 4                 # 256 CUs x 4 SIMD-32
 MAX_CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md "Max clock"
 ISSUE_CYCLES_PER_INST = 2.0     # a SIMD issues at most one wave64 instruction per 2 cycles (profiles/r02_valu_issue)
 ISSUE_PEAK_GINST = SIMDS * MAX_CLOCK_HZ / ISSUE_CYCLES_PER_INST / 1e9
-PMC_JSON = os.path.join(ROOT, "profiles", "r04_c2_kernel", "pmc_rz_render_samples.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r05_c2_kernel", "pmc_rz_render_samples.json")
 # Measured issue cost (SIMD cycles per wave64 instruction with four waves resident, profiles/r02_valu_issue/valu_issue.txt)
 # of the VALU classes the SQ counters tell apart; "other" = comparisons, selects, min / max, moves, lane reads.  The f32
 # add / mul / fma class mixes 2-cycle scalar-free forms with 3.5-cycle packed and SGPR-operand forms (2.6 assumed), int32
@@ -100,6 +110,10 @@ def parse(argv=None):
                          "ranks' device buffers (backend nccl = RCCL; also the automatic fallback if the group cannot be formed); "
                          "torch-gloo = rehearsal of the N>1 code path on a box with fewer GPUs than ranks (ranks share devices, "
                          "reduce staged through the host)")
+    ap.add_argument("--transport", choices=["reduce", "gather"], default="reduce",
+                    help="the group's exchange step: reduce = ONE ncclReduce(SUM) of the accumulation buffers (north_star; default), "
+                         "gather = each rank's own tiles sent straight to the root (ncclSend / ncclRecv; 1 / N of the bytes)")
+    ap.add_argument("--no-configs2", action="store_true", help="skip the extra BASELINE configs[2] (256 spp) leg of an N > 1 run")
     ap.add_argument("--loopback", action="store_true",
                     help="REHEARSAL of `--gpus N` as one plain process on a box with fewer GPUs: the N members of the group share "
                          "device 0 and device copies stand in for the links (RZ_GROUP_LOOPBACK); everything else -- the dealing of "
@@ -183,10 +197,33 @@ def main(argv=None):
     fp = frame_params(sc.camera, W, H, len(sc.lights), bounces, spp_total, 0, rank, world)
 
     group = None
+    transport_fallback = []         # why the run is not on the transport it was asked for (empty: it is)
+
+    def local_group(kind):
+        """One process, N devices.  kind: 'rccl' (contexts + communicators from ncclCommInitAll; the exchange step asked for),
+        'copies' (no communicator: tile gather by device copies between the members' GPUs), 'loopback' (rehearsal on device 0)."""
+        if kind == "loopback":
+            return rzdist.Group.create(world, [0] * world, flags | rzdist.GROUP_LOOPBACK)
+        if kind == "copies":
+            return rzdist.Group.create(world, list(range(world)), flags | rzdist.GROUP_LOOPBACK)
+        g = rzdist.Group.create(world, None, flags)
+        try:
+            g.set_transport(a.transport)
+        except Exception as e:      # (a bound RCCL without ncclSend / ncclRecv: the reduce is what it has)
+            transport_fallback.append(f"{a.transport} -> reduce: {e}")
+            g.set_transport("reduce")
+        return g
+
     if mode == "local-group":
-        # ONE process, N devices: the library makes the contexts and the communicators (ncclCommInitAll)
-        group = (rzdist.Group.create(world, [0] * world, flags | rzdist.GROUP_LOOPBACK) if a.loopback
-                 else rzdist.Group.create(world, None, flags))
+        if a.loopback:
+            group = local_group("loopback")
+        else:
+            try:
+                group = local_group("rccl")
+            except Exception as e:
+                print(f"[bench] the RCCL group cannot be made ({e}); the exchange step falls back to device copies between the GPUs", file=sys.stderr)
+                transport_fallback.append(f"rccl -> device copies: {e}")
+                group = local_group("copies")
     elif use_group:
         # Two steps, so that a rank which cannot even bind RCCL or make its context never leaves the others waiting inside
         # ncclCommInitRank: (1) every rank probes, all agree; (2) rank 0 makes the communicator id, everybody receives it over
@@ -223,57 +260,117 @@ def main(argv=None):
                     group.close()
                     group = None
                 use_group = False
+                transport_fallback.append("rz_group_create_rank failed on some rank -> torch.distributed.reduce")
+            else:
+                # every rank must use the SAME exchange step: the wish is the command line's, a rank whose RCCL cannot
+                # do it says so, and all ranks take the minimum (0 = reduce, 1 = gather)
+                can = torch.ones(1, dtype=torch.int32, device=dev)
+                if a.transport == "gather":
+                    try:
+                        group.set_transport("gather")
+                    except Exception as e:
+                        print(f"[bench] rank {rank}: no tile gather here ({e})", file=sys.stderr)
+                        can.zero_()
+                else:
+                    can.zero_()
+                dist.all_reduce(can, op=dist.ReduceOp.MIN)
+                group.set_transport("gather" if int(can.item()) == 1 else "reduce")
+                if a.transport == "gather" and int(can.item()) != 1:
+                    transport_fallback.append("gather -> reduce: some rank's RCCL has no ncclSend / ncclRecv")
         else:
             use_group = False
-    if group is not None:
-        group.upload_scene(sc)
-        group.set_frame(fp)             # tile_rank / tile_nranks are filled in by the group
-        members = [group.member(i) for i in range(group.local_count)]
-        r = members[0]
-        accum = frame = None
-    else:
-        r = Renderer(dev_index, flags)
-        members = [r]
-        r.upload_scene(sc)
+            transport_fallback.append("RCCL could not be bound / no context / no communicator id on some rank -> torch.distributed.reduce")
+    st = {"group": group, "r": None, "members": None, "accum": None, "frame": None}
+
+    def adopt():
+        """(Re)build the per-process render state around st['group'] (None: a plain context, with torch.distributed.reduce
+        as the exchange step in launcher mode)."""
+        g = st["group"]
+        if g is not None:
+            g.upload_scene(sc)
+            g.set_frame(fp)                 # tile_rank / tile_nranks are filled in by the group
+            st["members"] = [g.member(i) for i in range(g.local_count)]
+            st["r"] = st["members"][0]
+            st["accum"] = st["frame"] = None
+            return
+        rr = Renderer(dev_index, flags)
+        st["r"], st["members"] = rr, [rr]
+        rr.upload_scene(sc)
         if mode == "ranks":
-            accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)    # zero outside this rank's tiles
+            acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)    # zero outside this rank's tiles
             stream = torch.cuda.Stream(dev)     # the kernels, the reduce and the fences all order on this stream
             torch.cuda.set_stream(stream)
-            r.set_stream(stream.cuda_stream)
-            r.bind_accum(accum.data_ptr(), accum.numel() * 4)
-            # N > 1 rehearsal: `accum` is this rank's private buffer; each step copies it to `frame` and reduces THAT
-            frame = torch.empty_like(accum)
-        else:
-            accum = frame = None                # one GPU: the context's own accumulation buffer
-        r.set_frame(fp)
+            rr.set_stream(stream.cuda_stream)
+            rr.bind_accum(acc.data_ptr(), acc.numel() * 4)
+            # `accum` is this rank's private buffer; each step copies it to `frame` and reduces THAT
+            st["accum"], st["frame"] = acc, torch.empty_like(acc)
+        rr.set_frame(fp)
 
     def step():
-        if group is not None:
-            group.render()                  # asynchronous on the members' streams
-            group.reduce(0)                 # the frame's exchange step (tile gather: 1 / N of the 33-MB frame per member), enqueued behind the kernels
+        g = st["group"]
+        if g is not None:
+            g.render()                      # asynchronous on the members' streams
+            g.reduce(0)                     # the frame's exchange step, enqueued behind the kernels
             return
-        r.render()
+        st["r"].render()
         if mode == "ranks":
-            frame.copy_(accum)
+            st["frame"].copy_(st["accum"])
             if use_nccl:                    # torch path: one RCCL reduce(SUM) of the 33 MB frame
-                rzdist.reduce_accum(frame, dst=0)
+                rzdist.reduce_accum(st["frame"], dst=0)
             else:                           # rehearsal: same data flow, staged through the host
-                host = frame.cpu()
+                host = st["frame"].cpu()
                 rzdist.reduce_accum(host, dst=0)
                 if rank == 0:
-                    frame.copy_(host)
+                    st["frame"].copy_(host)
 
     def fence():
         # drain this process's own work first, so that the group's RCCL communicator and torch's (the barrier) are never
         # in flight together; then the barrier, then the device once more (the barrier itself runs on the GPU)
-        if group is not None:
-            group.sync()
+        if st["group"] is not None:
+            st["group"].sync()
         else:
-            r.sync()
+            st["r"].sync()
         if mode == "ranks":
             torch.cuda.synchronize(dev)
             dist.barrier()
             torch.cuda.synchronize(dev)
+
+    adopt()
+    # PROBE (untimed, before the warm-up): one whole step through the exchange.  A group whose exchange fails here is replaced,
+    # in this process, by the next transport down; nothing is re-executed, and the line says what happened.  (rz_group_reduce
+    # itself already falls back from the gather to the reduce; what arrives here is a reduce that failed too.)
+    if st["group"] is not None and not a.loopback:
+        ok_probe, why = True, ""
+        try:
+            step()
+            st["group"].sync()
+        except Exception as e:
+            ok_probe, why = False, str(e)
+        if mode == "ranks":
+            okt = torch.tensor([1 if ok_probe else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()) != 1:
+                print(f"[bench] rank {rank}: the group's exchange step failed on some rank ({why or 'not here'}); falling back to torch.distributed.reduce", file=sys.stderr)
+                transport_fallback.append(f"rz_group exchange failed in the probe step ({why or 'on another rank'}) -> torch.distributed.reduce")
+                try:
+                    st["group"].close()
+                except Exception:
+                    pass
+                st["group"], use_group = None, False
+                adopt()
+        elif not ok_probe:
+            print(f"[bench] the group's exchange step failed ({why}); rebuilding the group on device copies between the GPUs", file=sys.stderr)
+            transport_fallback.append(f"rccl exchange failed in the probe step ({why}) -> device copies")
+            try:
+                st["group"].close()
+            except Exception:
+                pass
+            st["group"] = local_group("copies")
+            adopt()
+        tp = st["group"].transport if st["group"] is not None else ""
+        if "fallback" in tp:
+            transport_fallback.append(tp)
+    group, r, members = st["group"], st["r"], st["members"]
 
     # untimed instrumented launches: exact algorithmic unit counts of this process's launches (all members of a local group)
     counters = None
@@ -312,16 +409,69 @@ def main(argv=None):
         dist.all_gather(allr, mine)
         rank_ms = [[float(x[0]), float(x[1])] for x in allr]
 
+    # the frame of the LAST timed step, before anything else is rendered
+    final = None
+    if rank == 0:
+        if group is not None:
+            final = group.read_frame()
+        elif mode == "ranks":
+            final = st["frame"].cpu().numpy()
+        else:
+            final = r.read_accum()
+
+    # N > 1: BASELINE configs[2] beside the headline -- the 256-spp frame on these N GPUs (strong scaling of THAT frame; at
+    # N = 8 it is configs[2] literally).  Three steps behind one warm-up step, same fences, same max over ranks.
+    configs2 = None
+    if world > 1 and not a.no_configs2 and not (a.spp_total == 256):
+        fp2 = frame_params(sc.camera, W, H, len(sc.lights), bounces, 256, 0, rank, world)
+        (group.set_frame if group is not None else r.set_frame)(fp2)
+        step()
+        fence()
+        for m in members:
+            m.render_history_ms()
+        c0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        fence()
+        e2 = time.perf_counter() - c0
+        k2 = max(float(np.mean(m.render_history_ms())) for m in members)
+        if mode == "ranks":
+            t = torch.tensor([e2, k2], dtype=torch.float64, device=dev if use_nccl else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e2, k2 = float(t[0].item()), float(t[1].item())
+        configs2 = {"workload": f"BASELINE configs[2]'s frame (same scene, {W}x{H}, 256 spp) tile-sharded across {world} GPU(s)"
+                                + ("" if world == 8 else f" -- configs[2] itself names 8 GPUs; this is its frame on {world}"),
+                    "is_baseline_configs2": bool(world == 8 and (W, H, bounces) == (1920, 1080, 4)),
+                    "scaling": "strong", "spp_total": 256, "steps": 3, "warmup": 1,
+                    "ms_per_step": round(e2 / 3 * 1e3, 3), "value": round(W * H * 256 * 3 / e2 / 1e6, 3), "unit": "Msamples/s",
+                    "slowest_kernel_ms": round(k2, 3)}
+        if rank == 0:
+            f2 = group.read_frame() if group is not None else (st["frame"].cpu().numpy() if mode == "ranks" else r.read_accum())
+            configs2["frame_check"] = {"every_pixel_has_256_samples": bool((f2[..., 3] == 256.0).all()),
+                                       "finite_and_nonnegative": bool(np.isfinite(f2).all() and (f2 >= 0).all())}
+
     total_samples = W * H * spp_total * a.steps
     value = total_samples / elapsed / 1e6
     ntri = int(sc.arrays[S.BIND_TRIANGLES].shape[0])
     cam = sc.camera
 
+    # what BASELINE.json calls this frame: configs[1] is the 64-spp frame on ONE GPU, configs[2] the 256-spp frame on 8; a
+    # weak-scaling frame of 64 x N spp is neither, and is labelled as what it is
+    std = (W, H, bounces, a.mesh_n) == (1920, 1080, 4, 76)
+    if std and world == 1 and spp_total == 64:
+        which_config = "configs[1]"
+    elif std and world == 8 and spp_total == 256:
+        which_config = "configs[2]"
+    elif std and scaling == "weak" and a.spp == 64:
+        which_config = (f"configs[1]'s scene and per-GPU work, WEAK scaling ({spp_total} spp per frame = 64 spp-equivalents per GPU; "
+                        f"BASELINE lists no {spp_total}-spp frame: configs[2], the 256-spp frame, is timed beside it as `configs2`)")
+    else:
+        which_config = "configs[1]'s scene (development override)"
     out = {
         "metric": "Msamples/s (rays x spp / s) at 1080p", "value": round(value, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[{2 if (world == 8 and spp_total == 256) else 1}]: {'OBJ mesh ' + os.path.basename(obj) if obj else 'bunny stand-in'} ({sc.name}, {ntri} tris incl. "
+        "config": {"workload": f"{which_config}: {'OBJ mesh ' + os.path.basename(obj) if obj else 'bunny stand-in'} ({sc.name}, {ntri} tris incl. "
                                f"floor) {W}x{H}, {spp_total} spp per frame ({spp_total // world if scaling == 'strong' else a.spp} "
                                f"spp-equivalents of work per GPU), {bounces} bounces, 2 lights",
                    "width": W, "height": H, "spp_per_gpu": a.spp, "spp_total": spp_total, "bounces": bounces, "triangles": ntri,
@@ -339,6 +489,11 @@ def main(argv=None):
         # frame per member, straight to the root; RZ_GROUP_TRANSPORT=reduce: one ncclReduce of the whole buffers)
         out["rccl_ranks"] = group.size if group is not None else 0
         out["transport"] = group.transport if group is not None else "torch.distributed.reduce"
+        out["transport_requested"] = a.transport
+        if transport_fallback:
+            out["transport_fallback"] = transport_fallback
+        if configs2 is not None:
+            out["configs2"] = configs2
         out["launch"] = mode + ("(loopback REHEARSAL: all members on device 0 -- not a scaling number)" if a.loopback else "")
         if reduce_ms is not None:
             out["reduce_ms"] = round(reduce_ms[0] if reduce_ms[0] >= 0 else reduce_ms[1], 3)
@@ -353,12 +508,6 @@ def main(argv=None):
         out["step_split_ms"] = {"slowest_kernel": round(slow_k, 3), "reduce": red, "step": out["ms_per_step"],
                                 "other": round(out["ms_per_step"] - slow_k - (red or 0.0), 3)}
     if rank == 0:
-        if group is not None:
-            final = group.read_frame()
-        elif mode == "ranks":
-            final = frame.cpu().numpy()
-        else:
-            final = r.read_accum()
         # size-independent check of the sharding + reduce: every pixel of the final frame received exactly
         # spp_total samples (a pixel rendered twice or not at all by the tile deal would show here)
         out["frame_check"] = {"every_pixel_has_spp_total_samples": bool((final[..., 3] == float(spp_total)).all()),
@@ -428,8 +577,10 @@ def main(argv=None):
         roof["work_model"] = wm
         if "executed_live_lane_valu" in roof:
             # the floor must lie below what the kernel executed on live lanes -- or the table over-prices a unit
+            # (recorded, not asserted: a mis-priced unit must not take the headline line down after the timed run -- ADVICE r4;
+            #  tests/test_workmodel.py enforces the inequality on the committed counter files)
             wm["floor_over_executed"] = round(wm["lane_slots"] / max(roof["executed_live_lane_valu"], 1), 4)
-            assert wm["lane_slots"] <= roof["executed_live_lane_valu"], (wm["lane_slots"], roof["executed_live_lane_valu"])
+            wm["floor_violated"] = bool(wm["lane_slots"] > roof["executed_live_lane_valu"])
         out["roofline"] = roof
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import rzo

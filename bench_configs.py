@@ -21,7 +21,7 @@
            and the rz_update of instances / TLAS nodes / TLAS indices.  Reported beside the 60-Hz budget (16.7 ms).
 bench.py stays the driver-facing benchmark (configs[1]); this prints one JSON line per config.  Every line carries the work
 model of rayzen_amd/workmodel.py (the FLOOR of VALU lane slots the algorithm needs / what the chip offers in the kernel's
-duration) and, when profiles/r04_<config>/pmc_rz_render_samples.json was captured from the loaded build, the measured fractions
+duration) and, when profiles/r05_<config>/pmc_rz_render_samples.json was captured from the loaded build, the measured fractions
 beside it (issue fraction, VALU lane utilisation, useful lane fraction, TA busy, instruction-cache hit rate), so the table of
 "which launch is furthest below its roof" comes from one command.
 """
@@ -33,6 +33,7 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(_
 
 
 ROOT = __import__("os").path.dirname(__import__("os").path.abspath(__file__))
+PROFILE_ROUND = "r05"
 PROFILE_OF = {"c4d": "c4", "c5": "c5", "c5d": "c5"}       # whose PMC file speaks for a row (same kernel launch)
 
 
@@ -41,7 +42,7 @@ def measured_fractions(name, kernel_s, wm):
     import os
     from rayzen_amd import _lib as rzlib
     from rayzen_amd.workmodel import LANE_PEAK, executed_live_lane_valu
-    path = os.path.join(ROOT, "profiles", "r04_" + PROFILE_OF.get(name, name), "pmc_rz_render_samples.json")
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_" + PROFILE_OF.get(name, name), "pmc_rz_render_samples.json")
     if not os.path.exists(path):
         return None
     pj = json.load(open(path))
@@ -59,7 +60,7 @@ def measured_fractions(name, kernel_s, wm):
         out["ta_busy"] = round(pj["TA_TA_BUSY_sum"] / (256.0 * pj["GRBM_GUI_ACTIVE"] / 8.0), 3)
     if pj.get("SQC_ICACHE_REQ"):
         out["icache_hit_rate"] = round(pj.get("SQC_ICACHE_HITS", 0.0) / pj["SQC_ICACHE_REQ"], 5)
-    assert wm["lane_slots"] <= live, (name, wm["lane_slots"], live)      # the floor lies below what the kernel executed on live lanes
+    out["floor_violated"] = bool(wm["lane_slots"] > live)       # the floor must lie below what the kernel executed on live lanes (enforced in tests/test_workmodel.py)
     return out
 
 

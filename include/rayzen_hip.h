@@ -99,7 +99,8 @@ typedef enum rz_status {
     RZ_ERR_NOT_READY      = -5,  /* render before all bindings / frame set */
     RZ_ERR_BAD_SCENE      = -6,  /* uploaded arrays are inconsistent */
     RZ_ERR_BUFFER_SIZE    = -7,  /* caller buffer too small */
-    RZ_ERR_NO_MEMORY      = -8   /* a host allocation failed inside the library (std::bad_alloc never crosses the ABI) */
+    RZ_ERR_NO_MEMORY      = -8,  /* a host allocation failed inside the library (std::bad_alloc never crosses the ABI) */
+    RZ_ERR_INTERNAL       = -9   /* a render kernel reached one of its "cannot happen" bounds: pixels may be missing (rz_sync reports it) */
 } rz_status;
 
 /* Per-frame parameters = the uniforms of sendSceneDataToShader
@@ -304,12 +305,16 @@ void* rz_stream_handle(rz_ctx* ctx);
  * and the teardown at main.cpp:681-686.  A group is that lifetime for N GPUs of one node: it owns one rz_ctx per LOCAL
  * device and the RCCL communicator(s), gives member m the tiles t with t % nranks == rank(m) (rz_frame_params.tile_rank
  * / tile_nranks are filled in by the group), and lands the frame on the root rank with ONE exchange step over xGMI,
- * issued on the members' render streams (no host synchronisation between the render kernel and the exchange): by
- * default a TILE GATHER -- every member packs the tiles it owns (1 / N of the frame) and sends them straight to the
- * root (ncclSend / ncclRecv), which scatters the N sets into the frame; bits are copied, never added.  With
- * RZ_GROUP_TRANSPORT=reduce in the environment (and when the bound RCCL lacks ncclSend / ncclRecv) it is ONE
- * ncclReduce(SUM) of the whole RGBA32F accumulation buffers: tile sets are disjoint and non-owned pixels are zero, so
- * the sum adds each pixel's single value to zeros.  Either way the frame is bit-identical to a single-GPU frame.
+ * issued on the members' render streams (no host synchronisation between the render kernel and the exchange).  Two
+ * exchange steps exist, both bit-identical to a single-GPU frame:
+ *   "reduce" (the default; BASELINE.json's "single RCCL reduce on the accumulation buffer"): ONE ncclReduce(SUM) of the
+ *            whole RGBA32F accumulation buffers -- tile sets are disjoint and non-owned pixels are zero, so the sum adds
+ *            each pixel's single value to zeros;
+ *   "gather" (RZ_GROUP_TRANSPORT=gather in the environment when the group is made, or rz_group_set_transport): every
+ *            member packs the tiles it owns (1 / N of the frame) and sends them straight to the root (ncclSend /
+ *            ncclRecv), which scatters the N sets into the frame; bits are copied, never added.  A gather whose enqueue
+ *            fails makes the group fall back to "reduce" for the rest of its life (the frame still lands).
+ * Every rank of a group must use the same one.
  *
  * Two ways to form a group:
  *   rz_group_create       one process drives ndev devices (ncclCommInitAll); ranks = 0..ndev-1, all local.
@@ -333,7 +338,8 @@ rz_group* rz_group_create_rank(int device, int rank, int nranks, const void* id1
 void      rz_group_destroy(rz_group* g);
 const char* rz_group_last_error(const rz_group* g);             /* g NULL: the error of a failed create */
 int       rz_group_size(const rz_group* g);                     /* ranks in the communicator */
-const char* rz_group_transport(const rz_group* g);              /* how rz_group_reduce moves the frame: "tile-gather(...)" | "rccl-reduce" */
+const char* rz_group_transport(const rz_group* g);              /* how rz_group_reduce moves the frame: "rccl-reduce" | "rccl-reduce(fallback: why)" | "tile-gather(...)" */
+int       rz_group_set_transport(rz_group* g, const char* name); /* "reduce" | "gather", from the next rz_group_reduce on; the same call on EVERY rank */
 int       rz_group_local_count(const rz_group* g);              /* members owned by this process */
 int       rz_group_rank(const rz_group* g, int local);          /* global rank of local member `local` */
 rz_ctx*   rz_group_ctx(rz_group* g, int local);                 /* the member's context (for per-device calls) */
@@ -359,6 +365,10 @@ int rz_group_last_reduce_ms(rz_group* g, float* root_ms, float* max_ms);
 int rz_group_read_frame(rz_group* g, float* rgba, size_t bytes);
 /* Device pointer of the reduced frame on the root member (NULL in other processes). */
 void* rz_group_frame_device_ptr(rz_group* g);
+
+/* TEST HOOK: set bits of the context's backstop word as a render kernel that ran into one of its bounds would; the next
+ * rz_sync returns RZ_ERR_INTERNAL naming them and clears the word. */
+int rz_debug_poke_backstop(rz_ctx* ctx, unsigned bits);
 
 /* TEST HOOK: the device-side scene layout as built (which = 0: DevPair[] 64 B each, 1: DevTri[] 48 B each;
  * rayzen_amd/csrc/hip/rz_scene_dev.h).  out NULL: only *needed is set.  Runs the pending re-layout first. */
@@ -386,6 +396,11 @@ int rz_device_count(void);
 
 /* Library/version probe that needs no GPU. */
 const char* rz_version(void);
+/* The ABI revision this library was compiled to: bumped whenever a struct of this header changes size or meaning
+ * (rz_counters grew in round 4 without one -- a caller built against the older header would have been written past).
+ * A binding compares it with RZ_ABI_VERSION of the header it was written against before its first call. */
+#define RZ_ABI_VERSION 5
+int rz_abi_version(void);
 /* sha256 (64 hex digits) of the sources and compiler flags this library was built from (rayzen_amd/build.py:
  * source_hash), or "unstamped": ties the LOADED library to a source tree and to a committed profile.  Needs no GPU. */
 const char* rz_source_hash(void);

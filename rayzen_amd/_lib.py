@@ -20,8 +20,9 @@ HIP_SYMBOLS = (
     "rz_group_rccl_version", "rz_group_unique_id", "rz_group_create", "rz_group_create_rank", "rz_group_destroy",
     "rz_group_last_error", "rz_group_size", "rz_group_local_count", "rz_group_rank", "rz_group_ctx", "rz_group_upload",
     "rz_group_update", "rz_group_set_frame", "rz_group_render", "rz_group_reduce", "rz_group_sync", "rz_group_read_frame",
-    "rz_group_frame_device_ptr", "rz_group_last_reduce_ms", "rz_group_transport",
+    "rz_group_frame_device_ptr", "rz_group_last_reduce_ms", "rz_group_transport", "rz_group_set_transport", "rz_abi_version", "rz_debug_poke_backstop",
 )
+ABI_VERSION = 5         # RZ_ABI_VERSION of the include/rayzen_hip.h this file mirrors
 # the symbols include/rayzen_host.h declares
 HOST_SYMBOLS = (
     "rzh_load_obj", "rzh_build_blas", "rzh_build_tlas", "rzh_world_bounds", "rzh_scene_create",
@@ -140,12 +141,21 @@ def hip():
         L.rz_group_sync.restype, L.rz_group_sync.argtypes = i, [vp]
         L.rz_group_read_frame.restype, L.rz_group_read_frame.argtypes = i, [vp, vp, sz]
         L.rz_group_frame_device_ptr.restype, L.rz_group_frame_device_ptr.argtypes = vp, [vp]
-        try:
-            L.rz_group_last_reduce_ms.restype, L.rz_group_last_reduce_ms.argtypes = i, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-            L.rz_group_transport.restype, L.rz_group_transport.argtypes = C.c_char_p, [vp]
-        except AttributeError:      # an A/B library built from an older revision (RAYZEN_HIP_SO): everything else still works
-            if not os.environ.get("RAYZEN_HIP_SO"):
-                raise
+        # (each in a try of its own: an A/B library built from an older revision (RAYZEN_HIP_SO) may lack any ONE of them, and
+        #  everything else must still work -- ADVICE r4)
+        for name, res, args in (("rz_group_last_reduce_ms", i, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+                                ("rz_group_transport", C.c_char_p, [vp]),
+                                ("rz_group_set_transport", i, [vp, C.c_char_p]),
+                                ("rz_abi_version", i, []), ("rz_debug_poke_backstop", i, [vp, C.c_uint])):
+            try:
+                fn = getattr(L, name)
+                fn.restype, fn.argtypes = res, args
+            except AttributeError:
+                if not os.environ.get("RAYZEN_HIP_SO"):
+                    raise
+        # the structs this file mirrors are the ones of ABI revision ABI_VERSION (include/rayzen_hip.h: RZ_ABI_VERSION)
+        if hasattr(L, "rz_abi_version") and L.rz_abi_version() != ABI_VERSION and not os.environ.get("RAYZEN_HIP_SO"):
+            raise RuntimeError(f"{HIP_SO} speaks ABI revision {L.rz_abi_version()}, this binding {ABI_VERSION}: rebuild (python -m rayzen_amd.build)")
         _hip = L
     return _hip
 

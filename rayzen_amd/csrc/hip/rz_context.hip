@@ -658,9 +658,18 @@ int finalize(rz_ctx* c) {
 // (rz_kernels.hip).  The one-lane-per-pixel kernel remains as RZ_FLAG_MEGAKERNEL (the literal, sequential form).
 bool use_samples(const rz_ctx* c) { return (c->flags & RZ_FLAG_MEGAKERNEL) == 0; }
 
+// The claim counter (word 0, zeroed per launch) and the backstop word (word RZ_ERRWORD, zeroed when made and when reported).
+int ensure_group_counter(rz_ctx* c) {
+    if (c->dGroupCtr.p) return RZ_OK;
+    int rc = ensure(c, c->dGroupCtr, 256);
+    if (rc != RZ_OK) return rc;
+    RZ_HIP(c, hipMemsetAsync(c->dGroupCtr.p, 0, 256, c->stream));
+    return RZ_OK;
+}
+
 int render_samples(rz_ctx* c, KParams K, bool counted, int evSlot) {
     K.nSlots = K.nLocalTiles * 64;
-    int rc = ensure(c, c->dGroupCtr, 256);
+    int rc = ensure_group_counter(c);
     if (rc != RZ_OK) return rc;
     K.groupCounter = static_cast<unsigned*>(c->dGroupCtr.p);
     // LDS budget: the BLAS stack's LDS window is cut to what keeps the target number of waves on a CU (16 for the
@@ -899,7 +908,8 @@ extern "C" {
 #endif
 static const char rz_stamp[] = "RZSRCHASH:" RZ_SOURCE_HASH;
 const char* rz_source_hash(void) { return rz_stamp + 10; }
-const char* rz_version(void) { return "rayzen_hip 0.3 (gfx950)"; }
+const char* rz_version(void) { return "rayzen_hip 0.5 (gfx950)"; }
+int rz_abi_version(void) { return RZ_ABI_VERSION; }
 
 int rz_device_count(void) {
     int n = 0;
@@ -1262,6 +1272,27 @@ int rz_sync(rz_ctx* c) {
     if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
     return guarded(c, "rz_sync", [&]() -> int {
         RZ_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->dGroupCtr.p) {       // did a kernel run into one of its "cannot happen" bounds?  (rz_kernels.hip: rz_backstop)
+            unsigned bits = 0;
+            unsigned* w = static_cast<unsigned*>(c->dGroupCtr.p) + RZ_ERRWORD;
+            RZ_HIP(c, hipMemcpy(&bits, w, sizeof bits, hipMemcpyDeviceToHost));
+            if (bits != 0u) {
+                RZ_HIP(c, hipMemset(w, 0, sizeof bits));
+                return fail(c, RZ_ERR_INTERNAL, "a render kernel reached a backstop (bits 0x%x:%s%s%s): pixels of the last frame(s) may be missing",
+                            bits, (bits & 1u) ? " claim without wait slots" : "", (bits & 2u) ? " pool did not drain" : "", (bits & 4u) ? " currentIor chains did not resolve" : "");
+            }
+        }
+        return RZ_OK;
+    });
+}
+
+int rz_debug_poke_backstop(rz_ctx* c, unsigned bits) {
+    if (!c) return fail(nullptr, RZ_ERR_INVALID_ARG, "null context");
+    return guarded(c, "rz_debug_poke_backstop", [&]() -> int {
+        int rc = ensure_group_counter(c);
+        if (rc != RZ_OK) return rc;
+        RZ_HIP(c, hipStreamSynchronize(c->stream));
+        RZ_HIP(c, hipMemcpy(static_cast<unsigned*>(c->dGroupCtr.p) + RZ_ERRWORD, &bits, sizeof bits, hipMemcpyHostToDevice));
         return RZ_OK;
     });
 }

@@ -4,12 +4,18 @@
 // :681-686 teardown) for N devices of one node.  Pixels shard by 8x8 tiles dealt round-robin (tile t -> rank t % N,
 // rz_frame_params.tile_rank / tile_nranks); each member renders ALL samples of its own pixels (currentIor couples a
 // pixel's samples, fragment_shader.glsl:674) into a buffer that is zero wherever it owns nothing.  The frame lands on the
-// root by a TILE GATHER (round 4, the default): every member packs the tiles it owns (1 KB each, 1 / N of the frame), sends
-// them straight to the root (ncclSend / ncclRecv: xGMI is point to point, the root has a link to every peer, and the seven
-// transfers of an 8-GPU node run side by side), and the root scatters the N packed sets into the frame.  At 1080p on 8 GPUs a
-// member moves 4.1 MB instead of taking part in a 33-MB ring reduce of which 7 / 8 is zeros.  Bits are copied, never added:
-// bit-identical to one GPU.  RZ_GROUP_TRANSPORT=reduce keeps rounds 1-3's ncclReduce(sum) of the whole buffers (one value
-// added to zeros: the same bits), and is what a group falls back to when the bound RCCL has no ncclSend / ncclRecv.
+// root by ONE exchange step, of which there are two:
+//   * "reduce" (THE DEFAULT again since round 5 -- it is what BASELINE.json's north_star names, and the simplest thing RCCL
+//     does): one ncclReduce(SUM, float, W * H * 4) of the whole accumulation buffers; tile sets are disjoint and non-owned
+//     pixels are zero, so every pixel's single value is added to zeros: bit-identical to one GPU;
+//   * "gather" (RZ_GROUP_TRANSPORT=gather or rz_group_set_transport(g, "gather"); round 4's default, demoted because it
+//     has never moved a byte between two GPUs): every member packs the tiles it owns (1 KB each, 1 / N of the frame), sends
+//     them straight to the root (ncclSend / ncclRecv: xGMI is point to point, the root has a link to every peer, and the
+//     seven transfers of an 8-GPU node run side by side), and the root scatters the N packed sets into the frame.  At 1080p
+//     on 8 GPUs a member moves 4.1 MB instead of taking part in a 33-MB ring reduce of which 7 / 8 is zeros.
+// A gather whose enqueue fails switches the group to "reduce" for the rest of its life and lands the SAME frame that way
+// (rz_group_transport() then reads "rccl-reduce(fallback: ...)"); every rank of a group must ask for the same transport --
+// one-process groups do by construction, a launcher agrees on it before the first frame (bench.py: all_reduce(MIN)).
 //
 // RCCL is bound with dlopen when the first group is made: librayzen_hip.so carries no DT_NEEDED on the 570-MB librccl,
 // a process that already has an RCCL mapped (e.g. through torch.distributed) shares that copy instead of running two
@@ -113,8 +119,11 @@ struct rz_group {
     std::vector<hipEvent_t> evBefore, evAfter;
     bool reduceTimed = false;
     // the tile gather: each member's packed tiles (on its device), the root's N packed sets (on the root's device)
-    bool gather = true;                 // false: ncclReduce of the whole buffers
-    bool loopback = false;              // RZ_GROUP_LOOPBACK: members share devices, device copies instead of RCCL
+    bool gather = false;                // true: the tile gather; false: ncclReduce of the whole buffers (the default)
+    bool loopback = false;              // RZ_GROUP_LOOPBACK: no communicator, device copies instead of RCCL (always the gather)
+    bool distinctDevices = false;       // loopback only: every member on a device of its own (copies cross xGMI), not a one-GPU rehearsal
+    std::string fallback;               // why a gather group fell back to the reduce (empty: it did not)
+    std::string transportText;          // rz_group_transport()'s answer
     std::vector<void*> packed;
     std::vector<size_t> packedBytes;
     std::vector<hipEvent_t> evSent;     // loopback: a member's packed tiles have reached the root's buffer
@@ -177,9 +186,9 @@ __global__ void rz_unpack_tiles(const float4* __restrict__ gathered, float4* __r
     frame[(size_t)py * width + px] = gathered[((size_t)r * perRank + lt) * 64 + ((py & 7) << 3 | (px & 7))];
 }
 
-bool transport_is_gather() {
+bool transport_is_gather() {            // the environment's wish; "reduce" unless it says gather
     const char* e = std::getenv("RZ_GROUP_TRANSPORT");
-    return !(e && std::strcmp(e, "reduce") == 0);
+    return e && std::strcmp(e, "gather") == 0;
 }
 
 void destroy_members(rz_group* g) {
@@ -341,13 +350,27 @@ rz_group* rz_group_create(int ndev, const int* devices, unsigned flags) {
         g->nranks = ndev;
         g->loopback = loopback;
         g->gather = loopback || (transport_is_gather() && g_rccl.Send && g_rccl.Recv);
+        if (loopback) {
+            g->distinctDevices = true;
+            for (int i = 0; i < ndev; ++i)
+                for (int j = 0; j < i; ++j)
+                    if (devices[i] == devices[j]) g->distinctDevices = false;
+        }
         for (int i = 0; i < ndev; ++i) {
             const int d = devices ? devices[i] : i;
             rz_ctx* c = rz_create(d, flags);
             if (!c) { gfail(nullptr, RZ_ERR_HIP, "rz_group_create: device %d: %s", d, rz_last_error(nullptr)); destroy_members(g); delete g; return nullptr; }
             g->ctx.push_back(c); g->rank.push_back(i); g->device.push_back(d); g->comm.push_back(nullptr);
         }
-        if (loopback) return g;         // (no communicator: device copies stand in for the links)
+        if (loopback) {                 // (no communicator: device copies stand in for the links)
+            // members on devices of their own: let the copies go straight over the links where the runtime allows it
+            // (failure is fine -- the copy is then staged; "already enabled" is fine too)
+            if (g->distinctDevices)
+                for (int i = 0; i < ndev; ++i)
+                    for (int j = 0; j < ndev; ++j)
+                        if (i != j && hipSetDevice(g->device[i]) == hipSuccess) { (void)hipDeviceEnablePeerAccess(g->device[j], 0); (void)hipGetLastError(); }
+            return g;
+        }
         ncclResult_t r = g_rccl.CommInitAll(g->comm.data(), ndev, g->device.data());
         if (r != ncclSuccess) {
             gfail(nullptr, RZ_ERR_HIP, "ncclCommInitAll(%d): %s", ndev, g_rccl.GetErrorString(r));
@@ -403,7 +426,25 @@ void rz_group_destroy(rz_group* g) {
 int rz_group_size(const rz_group* g) { return g ? g->nranks : 0; }
 const char* rz_group_transport(const rz_group* g) {
     if (!g) return "";
-    return !g->gather ? "rccl-reduce" : (g->loopback ? "tile-gather(loopback copies)" : "tile-gather(rccl send/recv)");
+    try {
+        std::string& t = const_cast<rz_group*>(g)->transportText;
+        if (g->gather) t = !g->loopback ? "tile-gather(rccl send/recv)" : (g->distinctDevices ? "tile-gather(device copies between the members' GPUs, no RCCL)" : "tile-gather(loopback copies)");
+        else t = g->fallback.empty() ? "rccl-reduce" : "rccl-reduce(fallback: " + g->fallback + ")";
+        return t.c_str();
+    } catch (...) { return g->gather ? "tile-gather" : "rccl-reduce"; }
+}
+// Which exchange step rz_group_reduce uses from now on: "reduce" or "gather".  EVERY rank of the group must make the same
+// call (a launcher agrees on it first); a loopback group has no communicator and always gathers.
+int rz_group_set_transport(rz_group* g, const char* name) {
+    if (!g) return gfail(nullptr, RZ_ERR_INVALID_ARG, "null group");
+    if (!name) return gfail(&g->err, RZ_ERR_INVALID_ARG, "rz_group_set_transport: null name");
+    const bool wantGather = std::strcmp(name, "gather") == 0;
+    if (!wantGather && std::strcmp(name, "reduce") != 0) return gfail(&g->err, RZ_ERR_INVALID_ARG, "rz_group_set_transport: \"%s\" (reduce | gather)", name);
+    if (g->loopback) return wantGather ? RZ_OK : gfail(&g->err, RZ_ERR_INVALID_ARG, "a loopback group has no communicator to reduce over");
+    if (wantGather && !(g_rccl.Send && g_rccl.Recv)) return gfail(&g->err, RZ_ERR_NOT_READY, "the bound RCCL (%s) has no ncclSend / ncclRecv", g_rccl.path.c_str());
+    try { g->fallback.clear(); } catch (...) { }
+    g->gather = wantGather;
+    return RZ_OK;
 }
 int rz_group_local_count(const rz_group* g) { return g ? (int)g->ctx.size() : 0; }
 int rz_group_rank(const rz_group* g, int local) { return (g && local >= 0 && local < (int)g->rank.size()) ? g->rank[local] : -1; }
@@ -480,8 +521,18 @@ int rz_group_reduce(rz_group* g, int root) {
     }
     if (g->gather) {
         const int rc = gather_tiles(g, root, rl);
-        if (rc != RZ_OK) return rc;
-    } else {
+        if (rc != RZ_OK) {
+            if (g->loopback) return rc;
+            // The gather could not be enqueued (an RCCL error from the send / receive group, a failed allocation): this group
+            // reduces from now on, and THIS frame lands through the reduce below -- same bits.  (Other processes of a rank-mode
+            // group do not see this rank's error: they would wait in their receive.  An enqueue failure of RCCL's is, in
+            // practice, a property of the build or the topology and hits every rank alike; the launcher should still agree
+            // on the transport up front.)
+            try { g->fallback = "the tile gather failed: " + g->err; } catch (...) { }
+            g->gather = false;
+        }
+    }
+    if (!g->gather) {
         // one collective per member, on the stream its render kernel was enqueued on; grouped so that one process
         // driving several devices cannot deadlock on launch order
         RZG_NCCL(g, g_rccl.GroupStart());

@@ -736,6 +736,15 @@ __device__ __forceinline__ bool may_hit_glass(const KParams& K, const bool cand,
 // glass -- rendered again with every unit resolved in the wave.
 // All scratch is private to the resident wave (L1 / L2 hits); the __syncthreads() of the one-wave workgroup order its stores
 // before its loads.
+// BACKSTOPS.  Three loops of the compacting launch carry bounds that "cannot be reached" -- and if an invariant were ever
+// violated they would leave pixels unrendered or unsummed with RZ_OK returned.  A wave that reaches one sets a bit of
+// the launch's error word (beside the claim counter); rz_sync reads the word and turns it into RZ_ERR_INTERNAL.
+//   1: a claim found fewer free wait slots than it has groups after the pool had been drained   2: the pool did not drain in
+//   (maxBounces + 1) passes   4: a transparent unit's chains did not resolve in 200 rounds
+__device__ __forceinline__ void rz_backstop(const KParams& K, unsigned code) {
+    if ((threadIdx.x & 63) == 0) atomicOr(K.groupCounter + RZ_ERRWORD, code);
+}
+
 template <bool COUNT, bool OVF, int UNITS, bool GLASS>
 __device__ __forceinline__ void render_claim_compact(const KParams& K, const ClaimMap M, const unsigned ci, const int nRedo, const int redoTop, unsigned char* lds_raw, int& wpN, int& freeCount) {
     using namespace poolf;
@@ -835,6 +844,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
 #endif
         // (every round gives each pixel's first blocked sample the version it lacks: at most 64 rounds per unit; the bound is a backstop)
         for (int round = 0; round < 200; ++round) {
+            if (GLASS && round == 199) rz_backstop(K, 4u);
             // (one exit, at the end of the body: see blas_walk)
             bool run, anyRun;
             {
@@ -1339,11 +1349,12 @@ __global__ __launch_bounds__(64, GLASS ? RZ_SAMPLES_MIN_WAVES_GLASS : RZ_SAMPLES
                 const int maxPasses = (K.maxBounces + 1) * (GLASS ? RZ_GLATE_CAP + 1 : 1);
                 for (int guard = 0; wpN > 0 && (!more || wpN >= (int)K.wpoolChunk || freeCount < need || K.drainEachClaim != 0) && guard <= maxPasses; ++guard)
                     wpN = pool_process<COUNT, OVF, GLASS>(K, K.wpool + (size_t)blockIdx.x * K.wpoolStride * RZ_GPOOL_FIELDS, K.wpoolStride, wpN, bstk, freeCount, redoCount, lateN);
+                if (wpN > 0 && (!more || freeCount < need)) rz_backstop(K, 2u);      // (cannot be: every pass ends paths)
                 if (!more) {
                     if (GLASS && redoCount > 0) continue;   // the last passes' groups to render again
                     break;
                 }
-                if (freeCount < need) break;   // (cannot be: see above -- but a claim must not run without its slots)
+                if (freeCount < need) { rz_backstop(K, 1u); break; }   // (cannot be: see above -- but a claim must not run without its slots; the claim's pixels stay unrendered and rz_sync says so)
             }
 #ifdef RZ_PROF
             ++wl_claims;

@@ -167,6 +167,7 @@ struct SamplesPlan { long long groups, grid; int perClaim; bool compact; int cla
 
 // The kernel is instantiated for claims of 8 and of 16 units (rz_kernels.hip: plan_render_samples picks by the size of the launch).
 constexpr int RZ_CLAIM_UNITS_SMALL = 8, RZ_CLAIM_UNITS_LARGE = 16;
+constexpr int RZ_ERRWORD = 16;          // KParams::groupCounter[RZ_ERRWORD]: the launch's backstop bits (rz_kernels.hip: rz_backstop; read by rz_sync)
 constexpr int RZ_POOL_FIELDS = 24;      // the parked path (13), its query (8), the items of a B phase (2), its currentIor (transparent scenes): rz_trace.h, namespace poolf
 constexpr int RZ_GPOOL_FIELDS = RZ_POOL_FIELDS + 1;     // a wave's pool: ... + the wait slot of the group a parked path belongs to (field 24)
 constexpr int RZ_SNAP_FIELDS = 19, RZ_SNAP_TALLY = 14;  // rz_path.h: snapshot_store -- a sample's state in front of its first transparent scatter (+ its tallies, counting launches)

@@ -178,8 +178,13 @@ class Group:
 
     @property
     def transport(self):
-        """How reduce() moves the frame: 'tile-gather(...)' or 'rccl-reduce' (rz_group_transport)."""
-        return self._L.rz_group_transport(self._g).decode()
+        """How reduce() moves the frame: 'rccl-reduce', 'rccl-reduce(fallback: ...)' or 'tile-gather(...)' (rz_group_transport)."""
+        fn = getattr(self._L, "rz_group_transport", None)
+        return fn(self._g).decode() if fn is not None and fn.restype is not None and fn.argtypes else "unknown (library predates rz_group_transport)"
+
+    def set_transport(self, name):
+        """'reduce' or 'gather' from the next reduce() on; every rank of the group must make the same call."""
+        self._check(self._L.rz_group_set_transport(self._g, name.encode()), "rz_group_set_transport")
 
     @property
     def local_count(self):

@@ -386,17 +386,56 @@ def stress_scene(n=289, aspect=16.0 / 9.0, blas_builder=None):
     return s.build()
 
 
+SUZANNE_HALF_EXTENTS = (1.367188, 0.984375, 0.851563)     # the AABB of RayZen/meshes/monkey.obj (507 vertices, 968 triangles), symmetric about 0
+
+
+def fit_to_box(tris, half_extents):
+    """Scale a mesh per axis so that its AABB is exactly +-half_extents about its own centre, moved to the origin."""
+    t = tris.copy()
+    pts = np.stack([t["v0"], t["v1"], t["v2"]]).reshape(-1, 3).astype(np.float64)
+    lo, hi = pts.min(0), pts.max(0)
+    c, k = (lo + hi) / 2.0, np.asarray(half_extents, np.float64) / ((hi - lo) / 2.0)
+    for f in ("v0", "v1", "v2"):
+        t[f] = ((t[f].astype(np.float64) - c) * k).astype(np.float32)
+    return t
+
+
+def camera_clearance(scene):
+    """Distance from the camera to the nearest instance WORLD box (main.cpp:974-993), 0 if it lies inside one.  RayZen's
+    camera stands outside every object of its scene; a stand-in mesh that swallows it renders a different frame (round 4's
+    `ref` rows did: VERDICT r4)."""
+    inst, nodes = scene.arrays[BIND_INSTANCES], scene.arrays[BIND_BLAS_NODES]
+    cam = np.asarray(scene.camera.position, np.float64)
+    best = np.inf
+    for it in inst:
+        root = nodes[int(it["blasNodeOffset"])]
+        if int(root["count"]) == 0 and int(root["leftFirst"]) == 0 and not np.all(np.isfinite(root["boundsMin"])):
+            continue
+        lo, hi = np.asarray(root["boundsMin"], np.float64), np.asarray(root["boundsMax"], np.float64)
+        if np.any(lo > hi):             # the empty mesh's inverted root box (BVH.cpp:115-118)
+            continue
+        m = np.asarray(it["transform"], np.float64).reshape(4, 4).T      # column-major -> row-major
+        corners = np.array([[x, y, z, 1.0] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])]) @ m.T
+        wlo, whi = corners[:, :3].min(0), corners[:, :3].max(0)
+        d = np.maximum(np.maximum(wlo - cam, cam - whi), 0.0)
+        best = min(best, float(np.sqrt((d * d).sum())))
+    return best
+
+
 def reference_scene(aspect=800.0 / 600.0, mesh_n=9):
     """RayZen's own scene (RayZen/src/main.cpp:331-384): camera (0, 0, 3) looking down -z, fov 70; the five materials and
     two lights of main.cpp:342-357; seven GameObjects, each with its OWN mesh (main.cpp:360-374 loads one Mesh per object,
     so nothing is shared): the cube floor scaled (8, .5, 8) at y = -3, five ~1 k-triangle meshes -- materials 1 (green
     metal), 2 (mirror), 0, 0 and 3 (GLASS, scaled 1.2) -- and one EMPTY mesh (`car.obj` is absent from the reference's
     meshes/, Mesh.cpp:8-11 logs an error and leaves the mesh empty).  monkey.obj (968 triangles) cannot travel to the GPU
-    box, so the stand-in is the 12 * mesh_n^2 = 972-triangle blob at Suzanne's size."""
+    box, so the stand-in is the 12 * mesh_n^2 = 972-triangle blob scaled per axis to SUZANNE'S EXTENTS (+-1.367, +-0.984,
+    +-0.852): the camera at z = 3 then stands 0.148 in front of the mesh at (0, 0, 4) and looks AWAY from it, as in RayZen's
+    frame -- half sky above a 16 x 16 floor, two meshes left and right, one ahead.  (Rounds 3-4 used a radius-1.0 blob whose
+    surface reaches 1.05: the camera sat INSIDE mesh D and every `ref` number described a closed room.  Retracted.)"""
     s = Scene(camera=Camera(position=(0.0, 0.0, 3.0), target=(0.0, 0.0, -1.0), aspect=aspect))
     I = identity()
     floor = s.add_mesh(make_cube(0))
-    monkey = lambda mat, seed: s.add_mesh(make_blob(mesh_n, 1.0, mat, seed=seed))
+    monkey = lambda mat, seed: s.add_mesh(fit_to_box(make_blob(mesh_n, 1.0, mat, seed=seed), SUZANNE_HALF_EXTENTS))
     a, b = monkey(1, 1), monkey(2, 2)
     car = s.add_mesh(np.zeros(0, TRIANGLE))
     c, d, glass = monkey(0, 3), monkey(0, 4), monkey(3, 5)
@@ -407,8 +446,11 @@ def reference_scene(aspect=800.0 / 600.0, mesh_n=9):
     s.add_object(c, translate(I, (0.0, 0.0, -4.0)))
     s.add_object(d, translate(I, (0.0, 0.0, 4.0)))
     s.add_object(glass, translate(scale(I, (1.2, 1.2, 1.2)), (2.5, 0.8, 2.5)))
-    s.name = f"rayzen-main-scene(7 objects, 12+5x{12 * mesh_n * mesh_n} tris)"
-    return s.build()
+    s.name = f"rayzen-main-scene(7 objects, 12+5x{12 * mesh_n * mesh_n} tris, Suzanne-sized stand-ins)"
+    s = s.build()
+    clear = camera_clearance(s)
+    assert clear > 0.1, f"reference_scene: the camera lies inside (or {clear:.3f} from) an instance's world box"
+    return s
 
 
 def hidden_glass_scene(n=76, aspect=16.0 / 9.0):

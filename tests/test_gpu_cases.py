@@ -426,3 +426,25 @@ def test_inverted_and_nan_child_boxes_take_the_generic_slab_test(flags):
     r.close()
     _eq(got, ref)
     _eq(counted, ref)
+
+
+@pytest.mark.gpu
+def test_a_kernel_backstop_is_reported_by_rz_sync():
+    """the persistent loop's "cannot happen" bounds (a claim without wait slots, a pool that does not drain, currentIor
+    chains that do not resolve) used to end in missing pixels with RZ_OK.  A wave that reaches one now sets a bit of the launch's
+    error word and rz_sync returns RZ_ERR_INTERNAL once, naming it -- checked through the hook that sets the word as a kernel
+    would; a normal frame leaves it clear."""
+    from rayzen_amd import _lib
+    from rayzen_amd.renderer import Renderer, RayZenError
+    L = _lib.hip()
+    sc = S.bunny_scene(n=8)
+    r = Renderer(0)
+    img = hip_render(sc, 64, 40, 64, 4, renderer=r)      # a compacting-capable launch shape, normal: no bits
+    r.sync()
+    assert L.rz_debug_poke_backstop(r._c, 2 | 4) == 0
+    with pytest.raises(RayZenError) as e:
+        r.sync()
+    assert e.value.code == -9 and "pool did not drain" in str(e.value) and "chains did not resolve" in str(e.value)
+    r.sync()                                             # reported once, then clear
+    assert (hip_render(sc, 64, 40, 64, 4, renderer=r).view(np.uint32) == img.view(np.uint32)).all()
+    r.close()

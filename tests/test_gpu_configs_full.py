@@ -375,3 +375,44 @@ def test_cross_claim_pool_continued_frames_tile_ranks_and_counters(monkeypatch):
     assert cnt == rc
     assert (img.view(np.uint32) == ref.view(np.uint32)).all()
     _band_check(sc, W, H, 128, b, whole)
+
+
+def test_rayzen_own_scene_full_frame_budget_1_then_5():
+    """RayZen's OWN frame (RayZen/src/main.cpp:331-384: camera (0, 0, 3), seven objects incl. the empty `car` mesh and the
+    glass monkey; 800 x 600, fragment_shader.glsl:675's one sample per pixel; bounce budget 1 on frame 0 and 5 afterwards,
+    main.cpp:600), with the TLAS / instances refreshed per frame as main.cpp:572 does: the WHOLE frame against the oracle,
+    both budgets.  The stand-in meshes have Suzanne's extents (rayzen_amd/scene.py: reference_scene), so the camera stands
+    outside every object -- round 4's stand-in swallowed it -- and half the frame is sky."""
+    from rayzen_amd.renderer import Renderer, frame_params
+    sc, W, H, spp, b = S.named_config("ref")
+    assert (W, H, spp, b) == (800, 600, 1, 5) and S.camera_clearance(sc) > 0.1
+    osc = oracle_scene(sc)
+    r = Renderer(0)
+    r.upload_scene(sc)
+    for budget in (1, 5):
+        sc.update_dynamic()
+        r.update_dynamic(sc)
+        r.set_frame(frame_params(sc.camera, W, H, len(sc.lights), budget, spp))
+        cnt = r.render_counted()
+        r.render()
+        gpu = r.read_accum()
+        ref, oc = rzo.render(osc, oracle_frame(sc, W, H, spp, budget), nthreads=16, want_counters=True)
+        assert (gpu.view(np.uint32) == ref.view(np.uint32)).all(), (budget, mismatch_report(gpu, ref))
+        hit = cnt["light_fetches"] / len(sc.lights) / cnt["samples"]
+        assert 0.3 < hit < 0.9, hit                      # an open scene: sky above the floor (a closed room reads 1.0)
+        for k in ("samples", "traversals", "tlas_nodes", "instances", "blas_nodes", "triangles", "materials", "light_fetches", "scatters"):
+            assert cnt[k] == oc[k], (budget, k, cnt[k], oc[k])
+    r.close()
+
+
+def test_rayzen_own_scene_at_16_spp_on_the_claims():
+    """The same scene at 16 samples per launch (`ref16`: the transparent scene through claims, pool, late list): full frame."""
+    sc, W, H, spp, b = S.named_config("ref16")
+    from rayzen_amd.renderer import Renderer
+    r = Renderer(0)
+    gpu = hip_render(sc, W, H, spp, b, renderer=r)
+    plan = r.debug_last_plan()
+    r.close()
+    assert plan["transparent"] == 1
+    ref = rzo.render(oracle_scene(sc), oracle_frame(sc, W, H, spp, b), nthreads=16)
+    assert (gpu.view(np.uint32) == ref.view(np.uint32)).all(), mismatch_report(gpu, ref)

@@ -132,6 +132,18 @@ def test_two_contexts_on_two_devices_interleaved():
     g.close()
     assert (frame.view(np.uint32) == ref.view(np.uint32)).all()
     assert root_ms >= 0.0 and max_ms >= root_ms
+    # ... the same through the tile gather (ncclSend / ncclRecv between the two devices), and through plain device copies
+    for make in (lambda: D.Group.create(2), lambda: D.Group.create(2, devices=[0, 1], flags=D.GROUP_LOOPBACK)):
+        g = make()
+        if not g.transport.startswith("tile-gather"):
+            g.set_transport("gather")
+        g.upload_scene(sc)
+        g.set_frame(frame_params(sc.camera, W, H, len(sc.lights), b, spp))
+        g.render(); g.reduce(1); g.sync()
+        frame = g.read_frame()
+        how = g.transport
+        g.close()
+        assert (frame.view(np.uint32) == ref.view(np.uint32)).all(), how
 
 
 @pytest.mark.gpu
@@ -163,22 +175,37 @@ def test_loopback_group_of_n_ranks_gathers_the_single_gpu_frame(nranks, root, si
 
 
 @pytest.mark.gpu
-def test_one_rank_group_with_the_reduce_transport(monkeypatch):
-    """RZ_GROUP_TRANSPORT=reduce: rounds 1-3's ncclReduce(sum) of the whole buffers is still there, same bits."""
+def test_one_rank_group_transports(monkeypatch):
+    """The default exchange step is north_star's ONE ncclReduce(sum) of the whole buffers (round 5; round 4 had made the never-run
+    tile gather the default).  RZ_GROUP_TRANSPORT=gather at creation, or rz_group_set_transport at any time, selects the gather;
+    the frame is the same bits either way, also when the transport changes between two chunks of one frame."""
     from rayzen_amd import scene as S
     from rayzen_amd.renderer import frame_params
     from helpers import oracle_render
-    monkeypatch.setenv("RZ_GROUP_TRANSPORT", "reduce")
     sc = S.bunny_scene(n=8, extras=True)
-    W, H, spp, b = 96, 54, 3, 4
+    W, H, b = 96, 54, 4
+    ref = oracle_render(sc, W, H, 5, b)
+    monkeypatch.delenv("RZ_GROUP_TRANSPORT", raising=False)
     g = D.Group.create(1)
     assert g.transport == "rccl-reduce"
     g.upload_scene(sc)
-    g.set_frame(frame_params(sc.camera, W, H, len(sc.lights), b, spp))
+    g.set_frame(frame_params(sc.camera, W, H, len(sc.lights), b, 2, 0))
+    g.render(); g.reduce(0)
+    g.set_transport("gather")
+    assert g.transport == "tile-gather(rccl send/recv)"
+    g.set_frame(frame_params(sc.camera, W, H, len(sc.lights), b, 3, 2))
     g.render(); g.reduce(0)
     got = g.read_frame()
+    with pytest.raises(Exception):
+        g.set_transport("carrier pigeon")
+    g.set_transport("reduce")
+    assert g.transport == "rccl-reduce"
     g.close()
-    assert (got.view(np.uint32) == oracle_render(sc, W, H, spp, b).view(np.uint32)).all()
+    assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+    monkeypatch.setenv("RZ_GROUP_TRANSPORT", "gather")
+    g = D.Group.create(1)
+    assert g.transport == "tile-gather(rccl send/recv)"
+    g.close()
 
 
 def test_loopback_is_refused_where_it_makes_no_sense():
@@ -188,6 +215,7 @@ def test_loopback_is_refused_where_it_makes_no_sense():
     assert not L.rz_group_create_rank(0, 0, 1, buf, D.GROUP_LOOPBACK)
     assert b"RZ_GROUP_LOOPBACK" in L.rz_group_last_error(None)
     assert L.rz_group_transport(None) == b""
+    assert L.rz_group_set_transport(None, b"reduce") != 0
 
 
 @pytest.mark.gpu

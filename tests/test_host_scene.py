@@ -306,3 +306,20 @@ def test_obj_mesh_replaces_the_stand_in_and_is_fitted_in_object_space(reference_
     assert abs(float(half.max()) - 2.8) < 1e-4 and np.allclose((v.max(axis=0) + v.min(axis=0)) * 0.5, 0, atol=1e-5)
     inst = sc.arrays[S.BIND_INSTANCES]
     assert np.allclose(inst["transform"][1].reshape(4, 4).T[:3, :3], np.eye(3))   # translation only: no scale in the transform
+
+
+def test_named_configs_keep_the_camera_outside_every_object():
+    """Every named workload's camera stands OUTSIDE every instance's world box (RayZen's does: camera (0, 0, 3), monkey D
+    centred at (0, 0, 4) reaches z = 3.148, RayZen/src/main.cpp:331-339, 383 + meshes/monkey.obj's extents).  Round 4's `ref`
+    rows were rendered from INSIDE a too-large stand-in mesh and described a closed room."""
+    import numpy as np
+    from rayzen_amd import scene as S
+    for name in ("c1", "c2", "c2close", "c2g", "c4", "ref", "ref64"):
+        sc = S.named_config(name)[0]
+        assert S.camera_clearance(sc) > 0.1, (name, S.camera_clearance(sc))
+    # the stand-in has Suzanne's box, exactly, and RayZen's triangle budget
+    sc = S.reference_scene()
+    inst, nodes = sc.arrays[S.BIND_INSTANCES], sc.arrays[S.BIND_BLAS_NODES]
+    root = nodes[int(inst[1]["blasNodeOffset"])]
+    assert np.allclose(root["boundsMax"], S.SUZANNE_HALF_EXTENTS, atol=1e-6) and np.allclose(root["boundsMin"], [-x for x in S.SUZANNE_HALF_EXTENTS], atol=1e-6)
+    assert sc.arrays[S.BIND_TRIANGLES].shape[0] == 12 + 5 * 972
