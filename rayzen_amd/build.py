@@ -79,11 +79,27 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     want = source_hash(extra_flags)
     if not force and stamped_hash(HIP_SO) == want:
         return HIP_SO
-    cmd = ([hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + [f'-DRZ_SOURCE_HASH="{want}"', "-I", INC, "-I", HIP_DIR, "-shared", "-o", HIP_SO]
-           + srcs + ["-ldl"])
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    # one object per source, compiled side by side (rz_kernels.hip alone is 80 s of the 115 s a single hipcc command takes), then linked
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    common = [hipcc_path()] + HIPCC_FLAGS + list(extra_flags) + [f'-DRZ_SOURCE_HASH="{want}"', "-I", INC, "-I", HIP_DIR]
+    with tempfile.TemporaryDirectory(prefix="rz_build_") as tmp:
+        objs = [os.path.join(tmp, os.path.basename(f) + ".o") for f in srcs]
+
+        def one(job):
+            src, obj = job
+            cmd = common + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+
+        with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as ex:
+            list(ex.map(one, zip(srcs, objs)))
+        link = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", HIP_SO + ".tmp"] + objs + ["-ldl"]
+        if verbose:
+            print(" ".join(link), file=sys.stderr)
+        subprocess.check_call(link)
+        os.replace(HIP_SO + ".tmp", HIP_SO)      # (a reader never sees a half-written library)
     return HIP_SO
 
 
