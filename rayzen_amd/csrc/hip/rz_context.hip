@@ -94,9 +94,6 @@ struct rz_ctx {
     bool geomDirty = true, instDirty = true, tlasDirty = true, matDirty = true, lightDirty = true;
 
     // device scene
-#ifdef RZ_ORDERED_WALK
-    DevBuf dKeyTab; int nKeyPairs = 0; long long keyTabFor = -1;
-#endif
     DevBuf dPairs, dTris, dInst, dTlasNodes, dTlasIdx, dMat, dLight, dCounters, dResolve, dGroupCtr, dBlasOvf;
     std::map<std::tuple<int, int, int>, BlasView> views;
     std::vector<DevPair> hPairs;
@@ -800,42 +797,6 @@ int do_render(rz_ctx* c, bool counted, rz_counters* out) {
     K.pairs = static_cast<const DevPair*>(c->dPairs.p);
     K.tris = static_cast<const DevTri*>(c->dTris.p);
     K.triN = static_cast<const DevTriN*>(c->dTriN.p);
-#ifdef RZ_ORDERED_WALK
-    {   // EXPERIMENT: pop-order numbers of the BLAS nodes, computed on the host from the laid-out pairs
-        const size_t nP = c->layoutOnDevice ? (size_t)c->devPairsUsed : c->hPairs.size();
-        const size_t nT = c->layoutOnDevice ? (size_t)c->devTrisUsed : c->hTris.size();
-        if (c->keyTabFor != (long long)(nP * 1000003ull + nT)) {
-            std::vector<DevPair> hp(std::max<size_t>(nP, 1));
-            RZ_HIP(c, hipStreamSynchronize(c->stream));
-            if (nP) RZ_HIP(c, hipMemcpy(hp.data(), c->dPairs.p, nP * sizeof(DevPair), hipMemcpyDeviceToHost));
-            std::vector<int32_t> tab(nP + nT + 1, 0);
-            for (auto& kv : c->views) {
-                const BlasView& V = kv.second;
-                if (V.empty) continue;
-                int counter = 1;
-                std::vector<int> st{V.rootEnc};
-                while (!st.empty()) {
-                    const int enc = st.back(); st.pop_back();
-                    if (enc >= 0) {
-                        tab[(size_t)V.pairBase + enc] = counter++;
-                        st.push_back(hp[(size_t)V.pairBase + enc].lenc);       // (popped second: the shader pops the right child first)
-                        st.push_back(hp[(size_t)V.pairBase + enc].renc);
-                    } else {
-                        const int slot = (~enc) >> 4;
-                        if (((~enc) & 15) > 0) tab[nP + (size_t)V.triBase + slot] = counter++;
-                    }
-                }
-            }
-            int rc2 = upload_vec(c, c->dKeyTab, tab.data(), tab.size() * sizeof(int32_t));
-            if (rc2 != RZ_OK) return rc2;
-            RZ_HIP(c, hipStreamSynchronize(c->stream));
-            c->nKeyPairs = (int)nP;
-            c->keyTabFor = (long long)(nP * 1000003ull + nT);
-        }
-        K.keyTab = static_cast<const int32_t*>(c->dKeyTab.p);
-        K.nKeyPairs = c->nKeyPairs;
-    }
-#endif
     K.instances = static_cast<const DevInstance*>(c->dInst.p);
     K.tlasDfs = static_cast<const TlasDfs*>(c->dTlasDfs.p);
     K.tlasIndices = static_cast<const int32_t*>(c->dTlasIdx.p);
@@ -1004,9 +965,6 @@ void rz_destroy(rz_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->dPairs, &c->dTris, &c->dInst, &c->dTlasNodes, &c->dTlasIdx, &c->dMat, &c->dLight,
                       &c->dCounters, &c->dResolve, &c->dGroupCtr, &c->dBlasOvf, &c->ownAccum, &c->dIor, &c->dXforms, &c->dInstRef, &c->dTlasScratch, &c->dProjBoxes, &c->dBuildWs, &c->dTlasDfs, &c->dTriN, &c->dRawNodes, &c->dRawIdx, &c->dRawTris, &c->dRelayoutWs, &c->dClaimScratch, &c->dWavePools, &c->dWaitMeta, &c->dSnap
-#ifdef RZ_ORDERED_WALK
-                      , &c->dKeyTab
-#endif
                       })
         b->release();
     if (c->tlasHostCounts) (void)hipHostFree(c->tlasHostCounts);

@@ -142,12 +142,6 @@ struct KParams {
     //      transparent scatter (rz_path.h: snapshot_store), from which the sample's second version starts; null: re-runs start at the camera
     float* snap;            // [resident wave][snapStride] floats
     uint32_t snapStride;    // >= (RZ_SNAP_FIELDS + RZ_SNAP_TALLY + RZ_GVER_ROWS) * 64 + RZ_GLATE_FIELDS * RZ_GLATE_CAP
-#ifdef RZ_ORDERED_WALK
-    // EXPERIMENT (profiles/r05_reconverge/): the pop-order number of every BLAS node -- [0, nKeyPairs) by absolute pair index
-    // (the node whose children the pair holds), [nKeyPairs, ...) by absolute first triangle slot of a leaf
-    const int32_t* keyTab;
-    int32_t nKeyPairs;
-#endif
 };
 
 // Arguments of the device TLAS rebuild (rz_tlas_device.hip: rz_tlas_refit; filled in by rz_context.hip).

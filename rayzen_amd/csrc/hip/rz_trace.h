@@ -590,129 +590,6 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
     return best;
 }
 
-#ifdef RZ_ORDERED_WALK
-// ---------------------------------------------------------------------------------------------------------------------
-// EXPERIMENT (profiles/r05_reconverge/): the BLAS walk with POP-ORDER RE-CONVERGENCE.
-// The shader's loop pops the nodes of a BLAS in an order that does not depend on the ray (depth first, right child before
-// left, FS:426-452): a ray only decides which subtrees it skips.  Every node and leaf carries its number in that order (the
-// key table, built on the host for this experiment).  The wave always steps the lanes that stand EARLIEST -- one group of
-// lanes at one node, fetched through the scalar cache -- and the others wait where they are: a lane's position only grows,
-// so the lanes behind either land on a waiting lane's node (and walk on together) or jump over it.  Lanes that part at one
-// pair meet again at the first node both visit; leaves are shared by all the lanes that ever test them.  Per lane the same
-// pops, the same culls against its own tLoc, the same tests in the same order: only WHEN a lane takes a step differs.
-template <bool COUNT, bool OVF, int OCT>
-__device__ __forceinline__ int blas_walk_ordered(const DevPair* __restrict__ pairs, const DevTri* __restrict__ tris, const int* __restrict__ keyP, const int* __restrict__ keyT,
-                                                 v3 lo, v3 ld, v3 inv, bool go, int cur, float& tLocOut, const BlasStackT<OVF>& bstk, Tally& c) {
-    float tLoc = 1e30f;
-    int best = -1, sp = 0;
-    const RayPk RP = make_raypk(lo, inv);
-    constexpr int INF = 0x7fffffff;
-    if (!go) cur = -1;
-#ifdef RZ_PROF
-    const unsigned long long tw0_ = __builtin_amdgcn_s_memtime();
-#endif
-    // a lane holds a node (cur >= 0 a pair, cur < -1 a leaf) or is through (cur == -1 with an empty stack): pops are eager
-    auto settle = [&]() {
-        unsigned long long pm = rz_ballot(cur == -1 && sp > 0);
-        while (pm != 0ull) {
-            if (in_mask(pm)) { if (!pop_entry(bstk, sp, tLoc, cur)) cur = -1; }
-            pm = rz_ballot(cur == -1 && sp > 0);
-        }
-    };
-    auto step = [&](bool hl, float tl, bool hr, float tr, int lenc, int renc) {
-        const bool takeR = hr && !(tr > tLoc);
-        if (hl && takeR) push_entry(bstk, sp, make_uint2((unsigned)lenc, __float_as_uint(tl)));
-        int next = takeR ? renc : ((tl > tLoc) ? -1 : lenc);
-        if (!hl && !takeR) next = -1;
-        cur = next;
-    };
-    unsigned guard = 0;
-    unsigned long long alive = rz_ballot(cur != -1);
-    while (alive != 0ull && ++guard < (1u << 24)) {
-        int u = __builtin_amdgcn_readlane(cur, (int)__builtin_ctzll(alive));
-        unsigned long long grp = alive;
-        int wmin = INF;
-        if (rz_ballot(cur != -1 && cur != u) != 0ull) {        // the lanes stand at different nodes: the earliest group goes
-            int key = INF;
-            if (cur != -1) key = cur >= 0 ? keyP[cur] : keyT[(~cur) >> 4];
-            // the smallest and the second smallest key among the groups, on the scalar unit: one trip per GROUP of lanes (two or
-            // three as a rule).  (Not a butterfly of lane shuffles: the wave runs this under partial exec masks -- lanes whose path
-            // has no query in this round -- and a shuffle through a masked-off lane reads zero and forwards nothing.)
-            int m = INF, m2 = INF, um = u;
-            unsigned long long rest = alive;
-            do {
-                const int l = (int)__builtin_ctzll(rest);
-                const int k = __builtin_amdgcn_readlane(key, l), cc = __builtin_amdgcn_readlane(cur, l);
-                if (k < m) { m2 = m; m = k; um = cc; } else if (k < m2) { m2 = k; }
-                rest &= ~rz_ballot(cur == cc);
-            } while (rest != 0ull);
-            u = um;
-            grp = rz_ballot(cur == u);
-            wmin = m2;
-        }
-        if (u >= 0) {
-            bool hl = false, hr = false, mixed;
-            float tl = 0.0f, tr = 0.0f;
-            int lenc, renc;
-            bool on;
-            do {
-#ifdef RZ_PROF
-                if (in_mask(grp)) { if (grp == alive) RZ_SITE(c, 7); else RZ_SITE(c, 3); }
-#endif
-                const f32x16 q = sload16_off(pairs, (unsigned)u << 6);
-                const f32x2 lx = {q[0], q[1]}, ly = {q[2], q[3]}, lz = {q[4], q[5]};
-                const f32x2 rx = {q[6], q[7]}, ry = {q[8], q[9]}, rz = {q[10], q[11]};
-                RZ_SLAB_PAIR(OCT, RP, lx, ly, lz, rx, ry, rz, hl, tl, hr, tr);
-                lenc = __float_as_int(q[12]); renc = __float_as_int(q[13]);
-                const unsigned long long mHl = rz_ballot(hl) & grp;
-                const unsigned long long mR = rz_ballot(hr) & ~rz_ballot(tr > tLoc) & grp;
-                if (COUNT) { if (in_mask(grp)) c.blas_nodes += 2; }
-                mixed = true;
-                if (mR == grp) {                    // everybody of the group goes on into the right child
-                    if (mHl != 0ull) { if (in_mask(mHl)) push_entry(bstk, sp, make_uint2((unsigned)lenc, __float_as_uint(tl))); }
-                    u = renc; mixed = false;
-                } else if (mR == 0ull && (mHl & ~rz_ballot(tl > tLoc)) == grp) {      // nobody does, everybody enters the left child
-                    u = lenc; mixed = false;
-                }
-                // the group walks on while it stays together, stands at a pair, and has not reached the earliest waiting lane
-                on = !mixed && u >= 0;
-                if (on && wmin != INF) on = sload1(keyP + u) < wmin;
-            } while (on);
-            if (in_mask(grp)) {
-                if (mixed) step(hl, tl, hr, tr, lenc, renc);
-                else cur = u;
-            }
-        } else {
-            // a leaf, tested by every lane that stands at it: its triangles come once through the scalar cache
-            const int uv = ~u, ufirst = uv >> 4, ucount = uv & 15;
-            if (in_mask(grp)) {
-                RZ_SITE(c, 1);
-                if (COUNT) c.triangles += (unsigned)ucount;
-                for (int k = 0; k < ucount; ++k) {
-                    RZ_SITE(c, 2);
-                    const float* __restrict__ tf = reinterpret_cast<const float*>(tris + ufirst + k);
-                    const f32x8 a = sload8(tf);
-                    const f32x4s b = sload4(tf + 8);
-                    float t;
-                    bool pastU;
-                    const bool hit = moller_trumbore(lo, ld, mk3(a[0], a[1], a[2]), mk3(a[3], a[4], a[5]), mk3(a[6], a[7], b[0]), t, pastU);
-                    if (COUNT && pastU) c.triangles_past_u += 1;
-                    if (hit && t < tLoc) { tLoc = t; best = ufirst + k; }
-                }
-                cur = -1;
-            }
-        }
-        settle();
-        alive = rz_ballot(cur != -1);
-        RZ_SITE(c, 0);
-    }
-#ifdef RZ_PROF
-    c.t[2] += __builtin_amdgcn_s_memtime() - tw0_;
-#endif
-    tLocOut = tLoc;
-    return best;
-}
-#endif
 
 #ifndef RZ_OCTANT_SLAB
 #define RZ_OCTANT_SLAB 1
@@ -748,21 +625,6 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
             const int first = __builtin_amdgcn_readlane(oct, (int)__builtin_ctzll(walkers));
             if (rz_ballot(go && (!fin || oct != first)) == 0ull) uoct = first;
         }
-#ifdef RZ_ORDERED_WALK
-        const int* keyP = K.keyTab + __float_as_int(r0[7]);
-        const int* keyT = K.keyTab + K.nKeyPairs + triBase;
-        switch (uoct) {
-            case 0: best = blas_walk_ordered<COUNT, OVF, 0>(pairs, tris, keyP, keyT, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-            case 1: best = blas_walk_ordered<COUNT, OVF, 1>(pairs, tris, keyP, keyT, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-            case 2: best = blas_walk_ordered<COUNT, OVF, 2>(pairs, tris, keyP, keyT, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-            case 3: best = blas_walk_ordered<COUNT, OVF, 3>(pairs, tris, keyP, keyT, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-            case 4: best = blas_walk_ordered<COUNT, OVF, 4>(pairs, tris, keyP, keyT, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-            case 5: best = blas_walk_ordered<COUNT, OVF, 5>(pairs, tris, keyP, keyT, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-            case 6: best = blas_walk_ordered<COUNT, OVF, 6>(pairs, tris, keyP, keyT, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-            case 7: best = blas_walk_ordered<COUNT, OVF, 7>(pairs, tris, keyP, keyT, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-            default: best = blas_walk_ordered<COUNT, OVF, -1>(pairs, tris, keyP, keyT, lo, ld, inv, go, cur, tLocOut, bstk, c); break;
-        }
-#else
         switch (uoct) {
             case 0: best = blas_walk<COUNT, OVF, 0, false>(pairs, tris, lo, ld, inv, go, cur, 0, 0, tLocOut, bstk, c); break;
             case 1: best = blas_walk<COUNT, OVF, 1, false>(pairs, tris, lo, ld, inv, go, cur, 0, 0, tLocOut, bstk, c); break;
@@ -774,15 +636,10 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
             case 7: best = blas_walk<COUNT, OVF, 7, false>(pairs, tris, lo, ld, inv, go, cur, 0, 0, tLocOut, bstk, c); break;
             default: best = blas_walk<COUNT, OVF, -1, false>(pairs, tris, lo, ld, inv, go, cur, 0, 0, tLocOut, bstk, c); break;
         }
-#endif
     } else
 #endif
     {
-#ifdef RZ_ORDERED_WALK
-        best = blas_walk_ordered<COUNT, OVF, -1>(pairs, tris, K.keyTab + __float_as_int(r0[7]), K.keyTab + K.nKeyPairs + triBase, lo, ld, inv, go, cur, tLocOut, bstk, c);
-#else
         best = blas_walk<COUNT, OVF, -1, false>(pairs, tris, lo, ld, inv, go, cur, 0, 0, tLocOut, bstk, c);
-#endif
     }
     return best < 0 ? -1 : best + triBase;
 }
