@@ -85,12 +85,21 @@ __device__ __forceinline__ bool rcp_mid_ok(float x) {       // false for NaN, ze
     const float a = __builtin_fabsf(x);
     return (a >= 0x1p-126f) & (a <= 0x1p126f);
 }
+#ifdef RZ_EXP_SLOW_OUT
+#define RZ_SLOWFN static __device__ __attribute__((noinline))
+#else
+#define RZ_SLOWFN __device__ __forceinline__
+#endif
+RZ_SLOWFN v3 rcp3_ieee(v3 d) { return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
+RZ_SLOWFN v3 div3_ieee(v3 a, float b) { return a / b; }
+RZ_SLOWFN float sqrt_ieee(float x) { return __builtin_sqrtf(x); }
+RZ_SLOWFN v3 normalize_ieee(v3 a, float d2) { return a / __builtin_sqrtf(d2); }
 // (1/x, 1/y, 1/z) of a ray direction
 __device__ __forceinline__ v3 rcp3(v3 d) {
     const bool okx = rcp_mid_ok(d.x), oky = rcp_mid_ok(d.y), okz = rcp_mid_ok(d.z);
     const bool ok = okx & oky & okz;
     if (rz_ballot(!ok) == 0ull) return mk3(rcp_mid(d.x), rcp_mid(d.y), rcp_mid(d.z));
-    return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    return rcp3_ieee(d);
 }
 
 // ---- quotients and square roots ---------------------------------------------
@@ -149,7 +158,7 @@ __device__ __forceinline__ v3 div3(v3 a, float b) {
         const float r = rcp_mid(b);
         return mk3(div_mid(a.x, b, r), div_mid(a.y, b, r), div_mid(a.z, b, r));
     }
-    return a / b;
+    return div3_ieee(a, b);
 }
 // GLSL length / normalize with their pinned definitions, sqrt(dot(v, v)) and v / sqrt(dot(v, v)): the square root and the three
 // quotients correctly rounded, by the short forms when the wave's operands allow (dot in [2^-100, 2^100] puts the length within
@@ -158,7 +167,7 @@ __device__ __forceinline__ v3 div3(v3 a, float b) {
 __device__ __forceinline__ float length(v3 a) {
     const float d2 = dot(a, a);
     if (rz_ballot(!sqrt_mid_ok(d2)) == 0ull) return sqrt_mid(d2);
-    return __builtin_sqrtf(d2);
+    return sqrt_ieee(d2);
 }
 __device__ __forceinline__ v3 normalize(v3 a) {
     const float d2 = dot(a, a);
@@ -167,7 +176,7 @@ __device__ __forceinline__ v3 normalize(v3 a) {
         const float r = rcp_mid(s);
         return mk3(div_mid(a.x, s, r), div_mid(a.y, s, r), div_mid(a.z, s, r));
     }
-    return a / __builtin_sqrtf(d2);
+    return normalize_ieee(a, d2);
 }
 
 // ---- sin / cos / acos -----------------------------------------------------
@@ -260,9 +269,17 @@ __device__ __forceinline__ float acos_(float xf) {
 }
 
 // FS:188-190
+#ifdef RZ_EXP_RAND_NOINLINE
+static __device__ __attribute__((noinline)) float sin_call(float x) { return sin_(x); }
+__device__ __forceinline__ float rand_(v2 uv) {
+    float d = uv.x * 12.9898f + uv.y * 78.233f;
+    return fract_(sin_call(d) * 43758.5453f);
+}
+#else
 __device__ __forceinline__ float rand_(v2 uv) {
     float d = uv.x * 12.9898f + uv.y * 78.233f;
     return fract_(sin_(d) * 43758.5453f);
 }
+#endif
 
 }  // namespace rz

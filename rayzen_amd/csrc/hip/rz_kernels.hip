@@ -601,6 +601,11 @@ __device__ __forceinline__ int kth_set_lane(unsigned long long m) {
 #ifndef RZ_SUM_UNROLL
 #define RZ_SUM_UNROLL 8
 #endif
+// The addends of a unit are written once and read once (1.5 KB per unit: 6.4 GB per C2 frame through an L2 they do not fit).
+// Non-temporal stores and loads for them were measured in round 5 and are 3 % SLOWER (C2 10.65 -> 10.98 ms,
+// C5 +1.4 %, c2g +2.9 %: the sums at the claim's end then wait for HBM instead of the L2): plain accesses (profiles/r05_regs/).
+#define RZ_ST_ADD(p, v) (*(p) = (v))
+#define RZ_LD_ADD(p) (*(p))
 template <bool COUNT, bool GLASS>
 __device__ __forceinline__ void ordered_sum_pass(const KParams& K, const bool valid, const float* __restrict__ A, const int slot, const int lane0) {
     const int lane = threadIdx.x & 63;
@@ -634,11 +639,11 @@ __device__ __forceinline__ void ordered_sum_pass(const KParams& K, const bool va
             for (; k + RZ_SUM_UNROLL <= cnt; k += RZ_SUM_UNROLL) {
                 float l[RZ_SUM_UNROLL], q8[RZ_SUM_UNROLL];
 #pragma unroll
-                for (int u = 0; u < RZ_SUM_UNROLL; ++u) { l[u] = Lf[k + u]; q8[u] = Sf[k + u]; }
+                for (int u = 0; u < RZ_SUM_UNROLL; ++u) { l[u] = RZ_LD_ADD(Lf + k + u); q8[u] = RZ_LD_ADD(Sf + k + u); }
 #pragma unroll
                 for (int u = 0; u < RZ_SUM_UNROLL; ++u) { chan = chan + l[u]; chan = chan + q8[u]; }   // FS:717, FS:709
             }
-            for (; k < cnt; ++k) { chan = chan + Lf[k]; chan = chan + Sf[k]; }
+            for (; k < cnt; ++k) { chan = chan + RZ_LD_ADD(Lf + k); chan = chan + RZ_LD_ADD(Sf + k); }
         }
     }
     const int l0 = q < 21 ? 3 * q : 0;
@@ -964,8 +969,8 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
         const unsigned long long pm = rz_ballot(parked);
         {
             float* const A = addBase + (size_t)g * GF + (size_t)b * 384;
-            A[lane] = P.addLight.x; A[64 + lane] = P.addLight.y; A[128 + lane] = P.addLight.z;        // FS:717
-            A[192 + lane] = P.addSky.x; A[256 + lane] = P.addSky.y; A[320 + lane] = P.addSky.z;       // FS:709 (parked: still 0)
+            RZ_ST_ADD(A + lane, P.addLight.x); RZ_ST_ADD(A + 64 + lane, P.addLight.y); RZ_ST_ADD(A + 128 + lane, P.addLight.z);        // FS:717
+            RZ_ST_ADD(A + 192 + lane, P.addSky.x); RZ_ST_ADD(A + 256 + lane, P.addSky.y); RZ_ST_ADD(A + 320 + lane, P.addSky.z);       // FS:709 (parked: still 0)
         }
         // compaction: parked lane -> pool position (paths already there) + (number of parked lanes below it)
         if (parked) {
@@ -1021,7 +1026,7 @@ __device__ __forceinline__ void render_claim_compact(const KParams& K, const Cla
         const int sl = __builtin_amdgcn_readlane(mySlot, g);
         const float* __restrict__ src = addBase + (size_t)g * GF;
         float* __restrict__ dst = slotsBase + (size_t)sl * GF;
-        for (int r = 0; r < (int)(GF >> 6); ++r) dst[r * 64 + lane] = src[r * 64 + lane];
+        for (int r = 0; r < (int)(GF >> 6); ++r) RZ_ST_ADD(dst + r * 64 + lane, RZ_LD_ADD(src + r * 64 + lane));
     }
     // ... and their pool entries learn the slot and their batch within the group
     for (int e0 = 0; e0 < nPool; e0 += 64) {
@@ -1173,7 +1178,7 @@ __device__ __forceinline__ int pool_process(const KParams& K, unsigned* __restri
         if (sl < n && !parked && !toList) {           // the path has ended: its sky term (FS:709; zero when it ended by roulette or budget) goes to its sample's place
             float* const A = slotsBase + (size_t)wslot * K.slotFloats + (size_t)((back >> 6) & 1023u) * 384;
             const unsigned bl = back & 63u;
-            A[192 + bl] = P.addSky.x; A[256 + bl] = P.addSky.y; A[320 + bl] = P.addSky.z;
+            RZ_ST_ADD(A + 192 + bl, P.addSky.x); RZ_ST_ADD(A + 256 + bl, P.addSky.y); RZ_ST_ADD(A + 320 + bl, P.addSky.z);
             if constexpr (GLASS) {
                 if (met) atomicOr(reinterpret_cast<unsigned*>(meta) + 2 * NS + wslot, FULL_REDO);       // no room on the list: the group is rendered again
                 if (P.gflag) slotsBase[(size_t)wslot * K.slotFloats + (size_t)nBatches * 384 + (spp >= 64 ? 0u : (bl / (unsigned)spp) * (unsigned)spp)] = P.ior;   // what this sample leaves its pixel (FS:742)

@@ -116,6 +116,15 @@ __device__ __forceinline__ v3 hemisphere_local(v2 seed) {
     sincos_(phi, sp, cp);
     return mk3(st * cp, st * sp, ct);
 }
+// ... and the same OUT OF LINE, for the opaque kernels (round 5, profiles/r05_regs/).  The draw runs for a twelfth of the scatters
+// (every other diffuse scatter draws the constant of bounce 0) and is 1 000 binary64 instructions with some forty live values:
+// inlined it shares the path's register allocation -- behind a call it has its own frame, the kernel is 2 400 instructions
+// shorter and C2 1.8 % faster (c2close -0.9 %, C5 -1.5 %).  The transparent kernels keep it inline: there the call's save /
+// restore lands on paths that are live across it more often (c2g +2.2 %, RayZen's scene at 64 spp +4.2 %).  Same operations either way.
+#ifndef RZ_HEMI_OUT_OF_LINE
+#define RZ_HEMI_OUT_OF_LINE 1
+#endif
+static __device__ __attribute__((noinline)) v3 hemisphere_local_call(v2 seed) { return hemisphere_local(seed); }
 __device__ __forceinline__ v3 hemisphere_world(v3 normal, v3 dir) {
     const v3 up = (__builtin_fabsf(normal.y) < 0.99f) ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
     const v3 tangent = normalize(cross(up, normal));
@@ -126,10 +135,11 @@ __device__ __forceinline__ v3 hemisphere_world(v3 normal, v3 dir) {
 // bounce 0 that is (+0, +0) for every pixel and every sample (seed > 0), so every first scatter draws the SAME local
 // direction.  It is computed once per context by rz_hemi0_kernel with this very function (K.hemi0) and the wave skips
 // the five binary64 evaluations -- 1.4 % of the C2 frame -- when all its lanes carry the zero seed (compared by bit pattern).
+template <bool GLASS>
 __device__ __forceinline__ v3 random_hemisphere_direction(const KParams& K, v3 normal, v2 seed) {
     const bool zero = __float_as_uint(seed.x) == 0u && __float_as_uint(seed.y) == 0u;
     v3 dir = mk3(K.hemi0[0], K.hemi0[1], K.hemi0[2]);
-    if (!zero) dir = hemisphere_local(seed);
+    if (!zero) dir = (RZ_HEMI_OUT_OF_LINE && !GLASS) ? hemisphere_local_call(seed) : hemisphere_local(seed);
     return hemisphere_world(normal, dir);
 }
 
@@ -317,7 +327,7 @@ __device__ __forceinline__ void scatter(const KParams& K, Path& P, Tally& c) {
 #ifdef RZ_PROF
                 const unsigned long long th0_ = __builtin_amdgcn_s_memtime();
 #endif
-                dir = random_hemisphere_direction(K, hitNormal, tempseed);
+                dir = random_hemisphere_direction<GLASS>(K, hitNormal, tempseed);
                 if (COUNT) { c.diffuse_scatters += 1; if (!(__float_as_uint(tempseed.x) == 0u && __float_as_uint(tempseed.y) == 0u)) c.hemi_draws += 1; }
 #ifdef RZ_PROF
                 c.t[8] += __builtin_amdgcn_s_memtime() - th0_;

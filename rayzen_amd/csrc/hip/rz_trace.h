@@ -102,6 +102,12 @@ __device__ __forceinline__ f32x4s sload4(const void* p) {
     asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
     return r;
 }
+// a 48-B record (a triangle, a 3x4 matrix, an instance's root box and bases) as dwordx8 + dwordx4 behind ONE wait (round 5: issued
+// as sload8 then sload4, each with its own wait, the second fetch's latency came on top of the first's: C2 -0.9 %, c2close -1.6 %,
+// RayZen's scene at 64 spp -1.5 %; profiles/r05_regs/)
+__device__ __forceinline__ void sload12(const void* p, f32x8& a, f32x4s& b) {
+    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
+}
 __device__ __forceinline__ int sload1(const void* p) {
     int r;
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
@@ -541,11 +547,23 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
                     if (rz_ballot(0 < count && cur != ucur) == 0ull) {
                         const int uv = ~ucur, ufirst = uv >> 4, ucount = uv & 15;
                         if (in_mask(triMask)) {
+#ifdef RZ_EXP_TRIPF
+                            // EXPERIMENT: triangle k + 1 is fetched while triangle k is tested (two register sets, the waits explicit)
+                            f32x8 na; f32x4s nb;
+                            asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20" : "=&s"(na), "=&s"(nb) : "s"(reinterpret_cast<const float*>(tris + ufirst)) : "memory");
+#endif
                             for (int k = 0; k < ucount; ++k) {
                                 RZ_SITE(c, 2);
                                 const float* __restrict__ tf = reinterpret_cast<const float*>(tris + ufirst + k);
-                                const f32x8 a = sload8(tf);
-                                const f32x4s b = sload4(tf + 8);
+                                f32x8 a;
+                                f32x4s b;
+#ifdef RZ_EXP_TRIPF
+                                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb) : : "memory");
+                                a = na; b = nb;
+                                if (k + 1 < ucount) asm volatile("s_load_dwordx8 %0, %2, 0x30\n\ts_load_dwordx4 %1, %2, 0x50" : "=&s"(na), "=&s"(nb) : "s"(tf) : "memory");
+#else
+                                sload12(tf, a, b);
+#endif
                                 float t;
                                 bool pastU;
                                 const bool hit = moller_trumbore(lo, ld, mk3(a[0], a[1], a[2]), mk3(a[3], a[4], a[5]), mk3(a[6], a[7], b[0]), t, pastU);
@@ -601,8 +619,9 @@ __device__ __forceinline__ int traverse_blas(const KParams& K, const DevInstance
     const v3 inv = rcp3(ld);
     if (COUNT) c.blas_nodes += 1;            // the shader pops the root
     // (I is wave-uniform: the instance's root box, root reference and bases come through the scalar cache)
-    const f32x8 r0 = sload8(I->rootMin);     // rootMin[3], rootEnc, rootMax[3], pairBase
-    const f32x4s r1 = sload4(&I->triBase);   // triBase, flags
+    f32x8 r0;                                // rootMin[3], rootEnc, rootMax[3], pairBase
+    f32x4s r1;                               // triBase, flags
+    sload12(I->rootMin, r0, r1);
     float tminRoot;
     bool go = slab(lo, inv, r0[0], r0[1], r0[2], r0[4], r0[5], r0[6], tminRoot);
     const int iflags = __float_as_int(r1[1]);
@@ -706,16 +725,18 @@ __device__ __forceinline__ bool trace_closest(const KParams& K, v3 o, v3 d, HitR
                     if (pass) {
                         if (COUNT) { c.tlas_leaf_indices += 1; c.instances += 1; }
                         RZ_SITE(c, 5);
-                        const f32x8 m0 = sload8(I->inv);
-                        const f32x4s m1 = sload4(I->inv + 8);
+                        f32x8 m0;
+                        f32x4s m1;
+                        sload12(I->inv, m0, m1);
                         const float mi[12] = {m0[0], m0[1], m0[2], m0[3], m0[4], m0[5], m0[6], m0[7], m1[0], m1[1], m1[2], m1[3]};
                         const v3 lo = x34_point(mi, o);
                         const v3 ld = normalize(x34_dir(mi, d));
                         float tLoc;
                         const int tri = traverse_blas<COUNT, OVF>(K, I, lo, ld, tLoc, bstk, c);
                         if (rz_ballot(tri >= 0) != 0ull) {
-                            const f32x8 f0 = sload8(I->fwd);
-                            const f32x4s f1 = sload4(I->fwd + 8);
+                            f32x8 f0;
+                            f32x4s f1;
+                            sload12(I->fwd, f0, f1);
                             const float mf[12] = {f0[0], f0[1], f0[2], f0[3], f0[4], f0[5], f0[6], f0[7], f1[0], f1[1], f1[2], f1[3]};
                             if (tri >= 0) {
                                 const v3 localHit = lo + ld * tLoc;              // FS:410
