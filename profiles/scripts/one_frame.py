@@ -9,6 +9,7 @@ from rayzen_amd import scene as S
 from rayzen_amd.renderer import Renderer, frame_params
 
 which = sys.argv[1] if len(sys.argv) > 1 else "c2"
+COUNTERS = sys.argv[sys.argv.index("--counters") + 1] if "--counters" in sys.argv else None      # also write rz_render_counted's tallies here (JSON)
 if which not in S.NAMED_CONFIGS:
     raise SystemExit(which)
 sc, W, H, SPP, B = S.named_config(which)
@@ -19,4 +20,9 @@ for _ in range(2):
     r.render()
 r.sync()
 print(which, [round(x, 3) for x in r.render_history_ms()])
+if COUNTERS:
+    import json
+    ms = r.render_history_ms()
+    cnt = r.render_counted()
+    json.dump({"config": which, "width": W, "height": H, "spp": SPP, "bounces": B, "counters": cnt}, open(COUNTERS, "w"))
 r.close()

@@ -85,12 +85,17 @@ __device__ __forceinline__ bool rcp_mid_ok(float x) {       // false for NaN, ze
     const float a = __builtin_fabsf(x);
     return (a >= 0x1p-126f) & (a <= 0x1p126f);
 }
-#ifdef RZ_EXP_SLOW_OUT
-#define RZ_SLOWFN static __device__ __attribute__((noinline))
-#else
+// The IEEE expansions behind the short forms' range votes are COLD (a wave takes them when one lane's operand is denormal, huge, zero
+// or NaN) and big (11-13 instructions per quotient or root, dozens of sites): out of line since round 5 -- the C2 kernel is 1 400
+// instructions shorter, 32 instead of 37 spilled VGPRs, C2 -0.8 %, C3 -0.9 %, C4 -1.0 %, c2g -1.3 % (RayZen's scene at 64 spp +1.0 %;
+// profiles/r05_regs/).  RZ_SLOW_PATHS_INLINE=1 restores the inlined form (A/B aid).
+#if defined(RZ_SLOW_PATHS_INLINE) && RZ_SLOW_PATHS_INLINE
 #define RZ_SLOWFN __device__ __forceinline__
+#else
+#define RZ_SLOWFN static __device__ __attribute__((noinline))
 #endif
 RZ_SLOWFN v3 rcp3_ieee(v3 d) { return mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
+__device__ __forceinline__ float rcp_ieee(float x) { return 1.0f / x; }
 RZ_SLOWFN v3 div3_ieee(v3 a, float b) { return a / b; }
 RZ_SLOWFN float sqrt_ieee(float x) { return __builtin_sqrtf(x); }
 RZ_SLOWFN v3 normalize_ieee(v3 a, float d2) { return a / __builtin_sqrtf(d2); }
@@ -269,17 +274,9 @@ __device__ __forceinline__ float acos_(float xf) {
 }
 
 // FS:188-190
-#ifdef RZ_EXP_RAND_NOINLINE
-static __device__ __attribute__((noinline)) float sin_call(float x) { return sin_(x); }
-__device__ __forceinline__ float rand_(v2 uv) {
-    float d = uv.x * 12.9898f + uv.y * 78.233f;
-    return fract_(sin_call(d) * 43758.5453f);
-}
-#else
 __device__ __forceinline__ float rand_(v2 uv) {
     float d = uv.x * 12.9898f + uv.y * 78.233f;
     return fract_(sin_(d) * 43758.5453f);
 }
-#endif
 
 }  // namespace rz

@@ -219,7 +219,7 @@ __device__ __forceinline__ bool moller_trumbore(v3 o, v3 d, v3 v0, v3 e1, v3 e2,
     // for the short reciprocal (NaN and infinities fail the comparison and take the division).
     float f;
     if (rz_ballot(!(__builtin_fabsf(a) <= 0x1p126f)) == 0ull) f = rcp_mid(a);
-    else f = 1.0f / a;
+    else f = rcp_ieee(a);
     v3 s = o - v0;
     float u = f * dot(s, h);
     // (every comparison is evaluated for every lane and the results are combined as lane masks: written as
@@ -319,7 +319,7 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
     // scalar registers), not per-lane `while (go && cur >= 0)` loops: for those hipcc keeps a mask of the lanes that
     // have left each loop level and spent more scalar instructions on exec-mask bookkeeping (~55 per descend step) than
     // vector instructions on the two box tests (~50) -- and the kernel is bound by instruction issue, scalar
-    // instructions included (DESIGN.md section 4.7).
+    // instructions included (DESIGN.md section 4.4).
 #ifdef RZ_PROF
     const unsigned long long tw0_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -547,23 +547,12 @@ __device__ __forceinline__ int blas_walk(const DevPair* __restrict__ pairs, cons
                     if (rz_ballot(0 < count && cur != ucur) == 0ull) {
                         const int uv = ~ucur, ufirst = uv >> 4, ucount = uv & 15;
                         if (in_mask(triMask)) {
-#ifdef RZ_EXP_TRIPF
-                            // EXPERIMENT: triangle k + 1 is fetched while triangle k is tested (two register sets, the waits explicit)
-                            f32x8 na; f32x4s nb;
-                            asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20" : "=&s"(na), "=&s"(nb) : "s"(reinterpret_cast<const float*>(tris + ufirst)) : "memory");
-#endif
                             for (int k = 0; k < ucount; ++k) {
                                 RZ_SITE(c, 2);
                                 const float* __restrict__ tf = reinterpret_cast<const float*>(tris + ufirst + k);
                                 f32x8 a;
                                 f32x4s b;
-#ifdef RZ_EXP_TRIPF
-                                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(na), "+s"(nb) : : "memory");
-                                a = na; b = nb;
-                                if (k + 1 < ucount) asm volatile("s_load_dwordx8 %0, %2, 0x30\n\ts_load_dwordx4 %1, %2, 0x50" : "=&s"(na), "=&s"(nb) : "s"(tf) : "memory");
-#else
                                 sload12(tf, a, b);
-#endif
                                 float t;
                                 bool pastU;
                                 const bool hit = moller_trumbore(lo, ld, mk3(a[0], a[1], a[2]), mk3(a[3], a[4], a[5]), mk3(a[6], a[7], b[0]), t, pastU);

@@ -16,8 +16,8 @@ is not a bound.  This one is a FLOOR:
   * what is NOT priced (address arithmetic, stacks, masks, claims, sky shading, mirror / glass scatter tails, Russian roulette,
     the ordered sums) is overhead by definition.
 
-So lane_slots <= the live-lane VALU instructions the kernel executed, on every launch (bench.py and bench_configs.py assert it
-whenever a PMC file of the same build is at hand), and
+So lane_slots <= the live-lane VALU instructions the kernel executed, on every launch (tests/test_workmodel.py holds it for every
+committed counter file; bench.py and bench_configs.py record `floor_violated` whenever a PMC file of the same build is at hand), and
 
     frac = lane_slots / (kernel duration x 1024 SIMDs x 32 lanes per cycle x 2.4 GHz)
 
@@ -92,7 +92,7 @@ def work_model(counters, kernel_s, n_chips=1):
             "slots_per_unit": SLOTS, "units": {k: int(v) for k, v in units.items()},
             "note": "FLOOR of VALU issue slots per lane the reference algorithm needs for THIS launch (rz_render_counted's tallies x the "
                     "table in rayzen_amd/workmodel.py: every instruction one slot, best known forms) / (kernel duration x 1024 SIMDs x 32 "
-                    "lanes x 2.4 GHz): rises only when the frame gets faster; bench.py asserts lane_slots <= the live-lane VALU instructions executed"}
+                    "lanes x 2.4 GHz): rises only when the frame gets faster; tests/test_workmodel.py holds lane_slots <= the live-lane VALU instructions executed on every committed counter file"}
 
 
 def executed_live_lane_valu(pmc):

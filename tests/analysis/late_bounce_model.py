@@ -6,9 +6,9 @@
 Model: a wavefront = the 64 samples of one pixel; it runs its paths' closest-hit queries in lock step, query k of every
 path together (what rz_render_samples does), and a query round costs the wave the MAXIMUM of its lanes' query costs
 (cost of a query = BLAS nodes/2 + 2 x triangles + 3, i.e. roughly its wave-level instruction count -- the kernel is
-bound by instruction issue, DESIGN.md section 4.7).  Printed per round: the lanes' summed work, the lock-step cost, and
+bound by instruction issue, DESIGN.md section 4.4).  Printed per round: the lanes' summed work, the lock-step cost, and
 the cost if the live lanes of the 8 pixels of one persistent claim were first compacted into full waves.
-Not a pytest file (no test_ prefix): an analysis tool whose output DESIGN.md section 7 quotes."""
+Not a pytest file (no test_ prefix): an analysis tool whose output HISTORY.md section 7 quotes."""
 import ctypes as C
 import os
 import sys

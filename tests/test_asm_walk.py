@@ -50,7 +50,9 @@ def _blocks(lines):
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", lines[i])
         if m:
             sym = m.group(1)
-        if "s_load_dwordx16 s[80:95]" in lines[i]:
+        # (the signature of the hand-written loop: the fetch into s[80:95] with the first plane subtraction straight behind the wait --
+        #  hipcc may give s[80:95] to a fetch of the C++ walk too)
+        if "s_load_dwordx16 s[80:95]" in lines[i] and any("v_pk_add_f32 v[6:7], s[80:81]" in l for l in lines[i + 1:i + 4]):
             blk = []
             j = i
             while j < len(lines) and j < i + 80:
