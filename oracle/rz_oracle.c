@@ -573,6 +573,9 @@ int rzo_shadow(const rzo_scene* scene, const float origin[3], const float dir[3]
     return shadow_visibility(&c, ld3(origin), ld3(dir), maxDist, visibility);
 }
 
+int rzo_math_flavour = 0;      /* rz_oracle_math.h: 0 = the pinned built-ins (always, except in tests/test_glref.py), 1 = llvmpipe's */
+void rzo_set_math_flavour(int f) { rzo_math_flavour = f; }
+int rzo_get_math_flavour(void) { return rzo_math_flavour; }
 float rzo_sin_f(float x) { return rzo_sin(x); }
 float rzo_cos_f(float x) { return rzo_cos(x); }
 float rzo_acos_f(float x) { return rzo_acos(x); }

@@ -107,7 +107,13 @@ typedef struct {
 int rzo_present(const rzo_scene* scene, const rzo_present_params* pp, const float* accum, float* rgb_out,
                 unsigned char* rgba8_out);
 
-/* The pinned built-ins, exported for the math tests. */
+/* Which sin / cos / acos the oracle evaluates (rz_oracle_math.h): 0 = the pinned ones (the default, what the product
+ * implements), 1 = Mesa llvmpipe's, so that frames of RayZen's own shader rendered by oracle/glref can be compared pixel by pixel
+ * at any bounce budget.  Process-wide; set it before rzo_render, not during one. */
+void rzo_set_math_flavour(int flavour);
+int rzo_get_math_flavour(void);
+
+/* The built-ins of the current flavour, exported for the math tests. */
 float rzo_sin_f(float x);
 float rzo_cos_f(float x);
 float rzo_acos_f(float x);

@@ -87,21 +87,21 @@ static inline double rzo_kcos(double r) {
     double h = __builtin_fma(z, -0.5, 1.0);
     return __builtin_fma(z * z, p, h);
 }
-static inline float rzo_sin(float x) {
+static inline float rzo_sin_pinned(float x) {
     int q; double r = rzo_reduce_pio2((double)x, &q);
     double s = rzo_ksin(r), c = rzo_kcos(r);
     double v = (q & 1) ? c : s;
     if (q & 2) v = -v;
     return (float)v;
 }
-static inline float rzo_cos(float x) {
+static inline float rzo_cos_pinned(float x) {
     int q; double r = rzo_reduce_pio2((double)x, &q);
     double s = rzo_ksin(r), c = rzo_kcos(r);
     double v = (q & 1) ? s : c;
     if (((q + 1) & 2) != 0) v = -v;
     return (float)v;
 }
-static inline float rzo_acos(float xf) {
+static inline float rzo_acos_pinned(float xf) {
     const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01,
                  pS2 = 2.01212532134862925881e-01, pS3 = -4.00555345006794114027e-02,
                  pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
@@ -137,5 +137,74 @@ static inline float rzo_acos(float xf) {
     }
     return (float)res;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * MATH FLAVOUR 1: sin / cos / acos as the GL implementation computes them that runs RayZen's own shader in oracle/glref
+ * (Mesa 23.2 llvmpipe on an x86-64 with FMA).  FOR ONE PURPOSE: with it, the oracle and RayZen's shader draw the SAME
+ * random numbers (FS:188-190: fract(sin(x) * 43758.5453), x up to 1e11 -- where an implementation's range reduction decides
+ * every bit), so frames of any bounce budget can be compared pixel by pixel (tests/test_glref.py), not only in
+ * distribution.  The default flavour 0 -- the pinned definitions above -- is what the product implements and what every
+ * parity test uses; the two flavours differ in these three functions and nowhere else.
+ *   sin, cos: gallivm's lp_build_sin_or_cos -- Cephes' sinf / cosf as in J. Pommier's sse_mathfun: octant j = (trunc(|x| * 4/pi)
+ *     + 1) & ~1 (x86 cvttps2dq: 0x80000000 out of range), three-constant Cody-Waite reduction and both polynomials with
+ *     FUSED multiply-adds (llvm.fmuladd on a machine with FMA), the result clamped to [-1, 1];
+ *   acos: Mesa's GLSL built-in, pi/2 - sign(x) (pi/2 - sqrt(1 - |x|) (pi/2 + |x| (pi/4 - 1 + |x| (p0 + |x| p1)))) in unfused binary32.
+ * Both were checked BIT FOR BIT against tables made by llvmpipe itself (oracle/glref/probe_math.glsl,
+ * tests/test_glref.py::test_flavour_1_is_llvmpipes_sin_cos_acos): 23 000 + 40 000 arguments, all ranges, all equal. */
+extern int rzo_math_flavour;
+
+static inline float rzo_lp_sincos(float xin, int want_cos) {
+    union { float f; unsigned u; } v, r;
+    v.f = xin;
+    unsigned sign_bit = want_cos ? 0u : (v.u & 0x80000000u);
+    v.u &= 0x7fffffffu;
+    const float x = v.f;
+    const float scale_y = x * 1.27323954473516f;
+    int j = (scale_y >= 2147483648.0f || scale_y != scale_y) ? (int)0x80000000 : (int)scale_y;
+    j = (int)(((unsigned)j + 1u) & ~1u);
+    const float y = (float)j;
+    unsigned swap, poly;
+    if (want_cos) {
+        const unsigned e = (unsigned)j - 2u;
+        swap = ((~e) & 4u) << 29;
+        poly = (e & 2u) == 0u;
+    } else {
+        swap = ((unsigned)j & 4u) << 29;
+        poly = ((unsigned)j & 2u) == 0u;
+    }
+    sign_bit ^= swap;
+    float xr = __builtin_fmaf(y, -0.78515625f, x);
+    xr = __builtin_fmaf(y, -2.4187564849853515625e-4f, xr);
+    xr = __builtin_fmaf(y, -3.77489497744594108e-8f, xr);
+    const float z = xr * xr;
+    float c = __builtin_fmaf(z, 2.443315711809948E-005f, -1.388731625493765E-003f);
+    c = __builtin_fmaf(c, z, 4.166664568298827E-002f);
+    c = c * z;
+    c = c * z;
+    c = c - z * 0.5f;
+    c = c + 1.0f;
+    float s = __builtin_fmaf(z, -1.9515295891E-4f, 8.3321608736E-3f);
+    s = __builtin_fmaf(s, z, -1.6666654611E-1f);
+    s = s * z;
+    s = __builtin_fmaf(s, xr, xr);
+    r.f = poly ? s : c;
+    r.u ^= sign_bit;
+    r.f = (r.f < 1.0f) ? r.f : 1.0f;        /* x86 minps / maxps: a NaN (x^2 overflowed) yields the bound */
+    r.f = (r.f > -1.0f) ? r.f : -1.0f;
+    return r.f;
+}
+static inline float rzo_lp_acos(float x) {
+    const float PIO2 = 1.57079632679489661923f, PIO4M1 = 0.78539816339744830962f - 1.0f;
+    const float ax = fabsf(x);
+    float e = 0.08132463f + ax * -0.02363318f;
+    e = PIO4M1 + ax * e;
+    e = PIO2 + ax * e;
+    const float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+    const float as = sgn * (PIO2 - sqrtf(1.0f - ax) * e);
+    return PIO2 - as;
+}
+static inline float rzo_sin(float x) { return rzo_math_flavour == 1 ? rzo_lp_sincos(x, 0) : rzo_sin_pinned(x); }
+static inline float rzo_cos(float x) { return rzo_math_flavour == 1 ? rzo_lp_sincos(x, 1) : rzo_cos_pinned(x); }
+static inline float rzo_acos(float x) { return rzo_math_flavour == 1 ? rzo_lp_acos(x) : rzo_acos_pinned(x); }
 
 #endif

@@ -90,6 +90,10 @@ def lib():
         for f in ("rzo_sin_f", "rzo_cos_f", "rzo_acos_f"):
             getattr(L, f).restype = C.c_float
             getattr(L, f).argtypes = [C.c_float]
+        L.rzo_set_math_flavour.restype = None
+        L.rzo_set_math_flavour.argtypes = [C.c_int]
+        L.rzo_get_math_flavour.restype = C.c_int
+        L.rzo_get_math_flavour.argtypes = []
         L.rzo_rand_f.restype = C.c_float
         L.rzo_rand_f.argtypes = [C.c_float, C.c_float]
         L.rzo_hemisphere_f.restype = None
@@ -158,6 +162,21 @@ def render(scene, frame, accum=None, ior_state=None, crop=None, nthreads=1, want
     if want_counters:
         return accum, {n: int(getattr(cnt, n)) for n in COUNTER_FIELDS}
     return accum
+
+
+class math_flavour:
+    """with rzo.math_flavour(1): ...  -- sin / cos / acos as Mesa llvmpipe computes them (rz_oracle_math.h), for comparisons
+    with frames of RayZen's own shader (tests/test_glref.py).  Everything else uses flavour 0, the pinned built-ins."""
+
+    def __init__(self, flavour):
+        self.flavour = int(flavour)
+
+    def __enter__(self):
+        self.old = lib().rzo_get_math_flavour()
+        lib().rzo_set_math_flavour(self.flavour)
+
+    def __exit__(self, *exc):
+        lib().rzo_set_math_flavour(self.old)
 
 
 def last_threads_busy():

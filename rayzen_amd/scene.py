@@ -422,7 +422,7 @@ def camera_clearance(scene):
     return best
 
 
-def reference_scene(aspect=800.0 / 600.0, mesh_n=9):
+def reference_scene(aspect=800.0 / 600.0, mesh_n=9, include_empty=True, monkey_obj=None):
     """RayZen's own scene (RayZen/src/main.cpp:331-384): camera (0, 0, 3) looking down -z, fov 70; the five materials and
     two lights of main.cpp:342-357; seven GameObjects, each with its OWN mesh (main.cpp:360-374 loads one Mesh per object,
     so nothing is shared): the cube floor scaled (8, .5, 8) at y = -3, five ~1 k-triangle meshes -- materials 1 (green
@@ -431,18 +431,26 @@ def reference_scene(aspect=800.0 / 600.0, mesh_n=9):
     box, so the stand-in is the 12 * mesh_n^2 = 972-triangle blob scaled per axis to SUZANNE'S EXTENTS (+-1.367, +-0.984,
     +-0.852): the camera at z = 3 then stands 0.148 in front of the mesh at (0, 0, 4) and looks AWAY from it, as in RayZen's
     frame -- half sky above a 16 x 16 floor, two meshes left and right, one ahead.  (Rounds 3-4 used a radius-1.0 blob whose
-    surface reaches 1.05: the camera sat INSIDE mesh D and every `ref` number described a closed room.  Retracted.)"""
+    surface reaches 1.05: the camera sat INSIDE mesh D and every `ref` number described a closed room.  Retracted.)
+    include_empty=False leaves the empty `car` object out: its BLAS root (count 0, inverted box) sends RayZen's shader into an
+    unbounded push loop over a 64-entry stack (FS:426-452: undefined behaviour), so a run of the REAL shader
+    (oracle/glref) can only be compared without it.  monkey_obj: path of the reference's own meshes/monkey.obj (build
+    container only) in place of the stand-ins."""
     s = Scene(camera=Camera(position=(0.0, 0.0, 3.0), target=(0.0, 0.0, -1.0), aspect=aspect))
     I = identity()
     floor = s.add_mesh(make_cube(0))
-    monkey = lambda mat, seed: s.add_mesh(fit_to_box(make_blob(mesh_n, 1.0, mat, seed=seed), SUZANNE_HALF_EXTENTS))
+    if monkey_obj is None:
+        monkey = lambda mat, seed: s.add_mesh(fit_to_box(make_blob(mesh_n, 1.0, mat, seed=seed), SUZANNE_HALF_EXTENTS))
+    else:
+        monkey = lambda mat, seed: s.add_mesh(load_obj(monkey_obj, mat))
     a, b = monkey(1, 1), monkey(2, 2)
-    car = s.add_mesh(np.zeros(0, TRIANGLE))
+    car = s.add_mesh(np.zeros(0, TRIANGLE)) if include_empty else None
     c, d, glass = monkey(0, 3), monkey(0, 4), monkey(3, 5)
     s.add_object(floor, translate(scale(I, (8.0, 0.5, 8.0)), (0.0, -3.0, 0.0)))
     s.add_object(a, translate(I, (-4.0, 0.0, 0.0)))
     s.add_object(b, translate(I, (4.0, 0.0, 0.0)))
-    s.add_object(car, translate(I, (0.0, 0.0, 0.0)))
+    if include_empty:
+        s.add_object(car, translate(I, (0.0, 0.0, 0.0)))
     s.add_object(c, translate(I, (0.0, 0.0, -4.0)))
     s.add_object(d, translate(I, (0.0, 0.0, 4.0)))
     s.add_object(glass, translate(scale(I, (1.2, 1.2, 1.2)), (2.5, 0.8, 2.5)))
