@@ -1,6 +1,7 @@
 /*
  * rz_oracle.c -- CPU restatement of RayZen's fragment-shader path tracer.
- * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see rz_oracle.h).
+ * TEST INFRASTRUCTURE ONLY.  PINNED against the reference itself: RayZen's own fragment shader run on Mesa llvmpipe
+ * (oracle/glref, tests/golden/glref_*.npz, tests/test_glref.py; see rz_oracle.h).
  *
  * Every function cites the lines of RayZen/shaders/fragment_shader.glsl
  * ("FS") it follows.  Statement order, operand order and the literal

@@ -3,10 +3,19 @@
  *
  * TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py's
  * cpu_baseline leg).  Nothing in the product path (rayzen_amd/, include/) may
- * include, link or call it.  PARITY UNPINNED: the reference holds no tests,
- * golden vectors or fixtures for this path, its GLSL renderer cannot run in
- * this container (no GL context) and its C++ host half cannot be compiled
- * (GLM is neither vendored nor installed), see DESIGN.md.
+ * include, link or call it.
+ *
+ * PARITY.  The reference holds no tests, golden vectors or fixtures for this
+ * path.  Its SHADER half (rz_oracle.c, rz_oracle_present.c) is PINNED against
+ * the reference itself, run here: oracle/glref loads RayZen's own GLSL from
+ * /root/reference and runs it on the OpenGL 4.5 implementation the image ships
+ * (Mesa llvmpipe); tests/golden/glref_*.npz hold 35 of its frames + a table of
+ * its sin / cos / acos, and tests/test_glref.py compares: pixel by pixel at any
+ * budget with math flavour 1 (llvmpipe's three built-ins replayed bit for bit),
+ * to rounding wherever no random number is drawn with the default flavour 0.
+ * Its HOST half (rz_oracle_bvh.c) stays UNPINNED beyond the node counts the
+ * survey recorded: BVH.cpp / Mesh.cpp / main.cpp need GLM (and GLFW / GLEW),
+ * neither vendored nor installed, and a stand-in is not allowed.  DESIGN.md 2.
  *
  * Plain C restatement of
  *   RayZen/shaders/fragment_shader.glsl ("FS") :188-212, 380-567, 569-663, 668-773

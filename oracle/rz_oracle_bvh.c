@@ -1,6 +1,6 @@
 /*
  * rz_oracle_bvh.c -- literal C restatement of RayZen's host-side input
- * producers.  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see rz_oracle.h):
+ * producers.  TEST INFRASTRUCTURE ONLY; THIS HALF'S PARITY IS UNPINNED (see rz_oracle.h):
  * the reference's BVH.cpp/Mesh.cpp need GLM, which is neither vendored nor
  * installed here, so they cannot be compiled as a cross-check; the only
  * reference outputs available are the node counts/depths the survey recorded

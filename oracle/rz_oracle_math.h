@@ -3,11 +3,13 @@
  * RayZen's path tracer (shaders/fragment_shader.glsl, "FS").
  *
  * TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
- * cpu_baseline leg may use anything under oracle/.  PARITY UNPINNED: the
- * reference has no tests or golden vectors for this path and its renderer
- * cannot run here (no GL context, no GLM); GLSL leaves the precision of
- * sin/cos/acos/pow/normalize to the driver.  The definitions below ARE the
- * specification both this oracle and the HIP kernels implement.
+ * cpu_baseline leg may use anything under oracle/.  GLSL leaves the precision
+ * of sin/cos/acos/pow/normalize to the driver; the definitions below ARE the
+ * specification both this oracle and the HIP kernels implement ("flavour 0").
+ * They were checked against RayZen's own shader run on Mesa llvmpipe
+ * (oracle/glref): wherever no random number is drawn the two agree to
+ * rounding, and with llvmpipe's sin / cos / acos swapped in (flavour 1, at
+ * the end of this file) they agree pixel by pixel at any bounce budget.
  *
  * Rules (SURVEY.md section 8a "numerics"):
  *   - all scene arithmetic is IEEE binary32, one rounding per operation,

@@ -7,7 +7,8 @@
  *                                               findBVHBranchIterative FS:257-307)
  *   FS:781-803  light markers
  *   FS:805-819  FPS overlay                    (font FS:118-146, drawFontChar FS:152-161, drawFpsString FS:164-183)
- * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see rz_oracle.h).  Same pinned numerics as rz_oracle.c: IEEE binary32,
+ * TEST INFRASTRUCTURE ONLY; pinned against RayZen's own shader run on Mesa llvmpipe (overlay frames of
+ * tests/golden/glref_rayzen_main.npz; see rz_oracle.h).  Same pinned numerics as rz_oracle.c: IEEE binary32,
  * one rounding per operation, no FMA, GLSL operand order; mat*mat and mat*vec sum their terms left to right;
  * smoothstep(e0,e1,x) = t*t*(3 - 2*t), t = clamp((x-e0)/(e1-e0),0,1); float->int conversions truncate.
  */

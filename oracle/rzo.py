@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg.  The product package (rayzen_amd/) never imports
-this module.  PARITY UNPINNED -- see oracle/rz_oracle.h.
+this module.  Pinned against RayZen's own shader run on Mesa llvmpipe (oracle/glref, tests/test_glref.py);
+the host half (BVH / OBJ / flatten) is unpinned beyond node counts -- see oracle/rz_oracle.h.
 """
 import ctypes as C
 import os

@@ -433,8 +433,8 @@ def reference_scene(aspect=800.0 / 600.0, mesh_n=9, include_empty=True, monkey_o
     frame -- half sky above a 16 x 16 floor, two meshes left and right, one ahead.  (Rounds 3-4 used a radius-1.0 blob whose
     surface reaches 1.05: the camera sat INSIDE mesh D and every `ref` number described a closed room.  Retracted.)
     include_empty=False leaves the empty `car` object out: its BLAS root (count 0, inverted box) sends RayZen's shader into an
-    unbounded push loop over a 64-entry stack (FS:426-452: undefined behaviour), so a run of the REAL shader
-    (oracle/glref) can only be compared without it.  monkey_obj: path of the reference's own meshes/monkey.obj (build
+    unbounded push loop over a 64-entry stack (FS:426-452: undefined behaviour), so a run of the REAL shader (the tests'
+    Mesa harness) can only be compared without it.  monkey_obj: path of the reference's own meshes/monkey.obj (build
     container only) in place of the stand-ins."""
     s = Scene(camera=Camera(position=(0.0, 0.0, 3.0), target=(0.0, 0.0, -1.0), aspect=aspect))
     I = identity()
