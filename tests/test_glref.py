@@ -207,3 +207,23 @@ def test_random_scenes_against_the_live_shader(seed):
     compare(oracle_fragcolor(sc, r, flavour=1), want, r, f"oracle[flavour 1] vs the live shader, seed {seed}", True)
     if b <= 2:
         compare(oracle_fragcolor(sc, r), want, r, f"oracle vs the live shader, seed {seed}", False)
+
+
+@pytest.mark.parametrize("config", ["rayzen 800x600", "bench 1920x1080"])
+def test_full_size_frames_against_the_live_shader(config):
+    """RayZen's own frame at RayZen's own size (main.cpp:27-28: 800 x 600, budget 5, its real monkey.obj) and the benchmark's
+    scene at 1080p (BASELINE configs[1]; the shader's one sample per pixel): the pixel coordinates -- and with them the hash's
+    arguments -- are those of the full-size frames, which the small fixtures do not reach."""
+    glref = _glref()
+    if config.startswith("rayzen"):
+        sc = S.reference_scene(include_empty=False, monkey_obj="/root/reference/RayZen/meshes/monkey.obj")
+        r = dict(W=800, H=600, budget=5, spp=1)
+    else:
+        sc, W, H, _, b = S.named_config("c2")
+        r = dict(W=W, H=H, budget=b, spp=1)
+    img, _ = glref.render_scene(sc, r["W"], r["H"], r["budget"])
+    want = np.ascontiguousarray(img[..., :3])
+    got = oracle_fragcolor(sc, r, flavour=1)
+    d = np.abs(got.astype(np.float64) - want).max(axis=-1)
+    assert (d > 1e-4).sum() <= 1e-5 * d.size + 2, f"{config}: {(d > 1e-4).sum()} pixels of {d.size} beyond 1e-4, Linf {d.max():.3e}"
+    assert (got.view(np.uint32) == want.view(np.uint32)).all(axis=-1).mean() > 0.4
