@@ -584,7 +584,8 @@ def main(argv=None):
         out["roofline"] = roof
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import rzo
-        from helpers import oracle_frame, oracle_scene
+        from helpers import oracle_frame, oracle_scene, sync_oracle_flavour
+        out["math_flavour"] = sync_oracle_flavour()      # the oracle evaluates sin / cos / acos as the loaded library does (rz_math_flavour())
         ncores = a.cpu_threads if a.cpu_threads > 0 else min(16, len(os.sched_getaffinity(0)))
         osc = oracle_scene(sc)
         ofr = oracle_frame(sc, W, H, a.spp, bounces)
@@ -628,7 +629,8 @@ def main(argv=None):
         # landed on rank 0, against the oracle at the frame's full sample count: tiles that arrived in the wrong place would
         # pass frame_check (every pixel has the same sample count) and fail here
         from oracle import rzo
-        from helpers import oracle_frame, oracle_scene
+        from helpers import oracle_frame, oracle_scene, sync_oracle_flavour
+        out["math_flavour"] = sync_oracle_flavour()      # the oracle evaluates sin / cos / acos as the loaded library does (rz_math_flavour())
         ncores = a.cpu_threads if a.cpu_threads > 0 else min(16, len(os.sched_getaffinity(0)))
         osc = oracle_scene(sc)
         ofr = oracle_frame(sc, W, H, spp_total, bounces)

@@ -401,6 +401,12 @@ const char* rz_version(void);
  * A binding compares it with RZ_ABI_VERSION of the header it was written against before its first call. */
 #define RZ_ABI_VERSION 5
 int rz_abi_version(void);
+/* Which implementation of the three built-ins GLSL leaves open -- sin, cos, acos; RayZen's hash is fract(sin(x) * 43758.5453)
+ * (fragment_shader.glsl:188-190) -- this library was compiled with (rz_device_math.h, RZ_MATH_FLAVOUR): 1 = Mesa llvmpipe's, the
+ * OpenGL implementation RayZen's own shader was run on for this project's parity tests (binary32 Cephes sin / cos with fused
+ * multiply-adds, Mesa's acos polynomial); 0 = binary64 evaluation rounded once (correctly rounded).  A frame is a function of this
+ * choice from the third path segment on.  Needs no GPU. */
+int rz_math_flavour(void);
 /* sha256 (64 hex digits) of the sources and compiler flags this library was built from (rayzen_amd/build.py:
  * source_hash), or "unstamped": ties the LOADED library to a source tree and to a committed profile.  Needs no GPU. */
 const char* rz_source_hash(void);

@@ -574,7 +574,7 @@ int rzo_shadow(const rzo_scene* scene, const float origin[3], const float dir[3]
     return shadow_visibility(&c, ld3(origin), ld3(dir), maxDist, visibility);
 }
 
-int rzo_math_flavour = 0;      /* rz_oracle_math.h: 0 = the pinned built-ins (always, except in tests/test_glref.py), 1 = llvmpipe's */
+int rzo_math_flavour = 1;      /* rz_oracle_math.h: 1 = llvmpipe's sin / cos / acos (what the product is compiled with by default), 0 = rounds 1-4's binary64 ones; tests/helpers.py sets it to the loaded library's */
 void rzo_set_math_flavour(int f) { rzo_math_flavour = f; }
 int rzo_get_math_flavour(void) { return rzo_math_flavour; }
 float rzo_sin_f(float x) { return rzo_sin(x); }

@@ -11,8 +11,9 @@
  * /root/reference and runs it on the OpenGL 4.5 implementation the image ships
  * (Mesa llvmpipe); tests/golden/glref_*.npz hold 35 of its frames + a table of
  * its sin / cos / acos, and tests/test_glref.py compares: pixel by pixel at any
- * budget with math flavour 1 (llvmpipe's three built-ins replayed bit for bit),
- * to rounding wherever no random number is drawn with the default flavour 0.
+ * budget with math flavour 1 (llvmpipe's three built-ins replayed bit for bit:
+ * the default, and the product's), to rounding wherever no random number is
+ * drawn with flavour 0 (rounds 1-4's binary64 built-ins).
  * Its HOST half (rz_oracle_bvh.c) stays UNPINNED beyond the node counts the
  * survey recorded: BVH.cpp / Mesh.cpp / main.cpp need GLM (and GLFW / GLEW),
  * neither vendored nor installed, and a stand-in is not allowed.  DESIGN.md 2.
@@ -116,9 +117,10 @@ typedef struct {
 int rzo_present(const rzo_scene* scene, const rzo_present_params* pp, const float* accum, float* rgb_out,
                 unsigned char* rgba8_out);
 
-/* Which sin / cos / acos the oracle evaluates (rz_oracle_math.h): 0 = the pinned ones (the default, what the product
- * implements), 1 = Mesa llvmpipe's, so that frames of RayZen's own shader rendered by oracle/glref can be compared pixel by pixel
- * at any bounce budget.  Process-wide; set it before rzo_render, not during one. */
+/* Which sin / cos / acos the oracle evaluates (rz_oracle_math.h): 1 = Mesa llvmpipe's (the default, and what the product is
+ * compiled with: rz_math_flavour()), with which frames of RayZen's own shader rendered by oracle/glref agree pixel by pixel at any
+ * bounce budget; 0 = rounds 1-4's binary64, correctly rounded ones (the product's -DRZ_MATH_FLAVOUR=0 build).  Process-wide; set
+ * it before rzo_render, not during one. */
 void rzo_set_math_flavour(int flavour);
 int rzo_get_math_flavour(void);
 

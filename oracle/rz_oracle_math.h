@@ -1,29 +1,31 @@
 /*
- * rz_oracle_math.h -- the pinned definitions of the GLSL built-ins used by
- * RayZen's path tracer (shaders/fragment_shader.glsl, "FS").
+ * rz_oracle_math.h -- the definitions of the GLSL built-ins used by RayZen's
+ * path tracer (shaders/fragment_shader.glsl, "FS").
  *
  * TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
- * cpu_baseline leg may use anything under oracle/.  GLSL leaves the precision
- * of sin/cos/acos/pow/normalize to the driver; the definitions below ARE the
- * specification both this oracle and the HIP kernels implement ("flavour 0").
- * They were checked against RayZen's own shader run on Mesa llvmpipe
- * (oracle/glref): wherever no random number is drawn the two agree to
- * rounding, and with llvmpipe's sin / cos / acos swapped in (flavour 1, at
- * the end of this file) they agree pixel by pixel at any bounce budget.
+ * cpu_baseline leg may use anything under oracle/.
  *
- * Rules (SURVEY.md section 8a "numerics"):
+ * Rules (SURVEY.md section 8a "numerics"), confirmed against RayZen's own
+ * shader run on Mesa llvmpipe (oracle/glref; llvmpipe's + - * / sqrt
+ * inversesqrt are IEEE and unfused: probe_math.glsl):
  *   - all scene arithmetic is IEEE binary32, one rounding per operation,
  *     evaluated left to right, NO fused multiply-add (compile with
  *     -ffp-contract=off);
  *   - division and sqrt are correctly rounded;
  *   - min/max are IEEE-754 minNum/maxNum (the non-NaN operand wins), which
  *     is what GPU min/max instructions do;
- *   - sin/cos/acos are computed in binary64 from + - * / sqrt fma floor rint
- *     only (all exactly specified by IEEE-754, hence bit-identical on any
- *     conforming CPU or GPU) and rounded once to binary32.  The polynomial
- *     coefficients are the published fdlibm (FreeBSD msun k_sin.c, k_cos.c,
- *     e_acos.c) minimax coefficients; the argument reduction is a 3-term
- *     Cody-Waite split of pi/2 applied with fma.
+ *   - sin/cos/acos -- left to the implementation by GLSL, and decisive: FS's
+ *     hash is fract(sin(x) * 43758.5453) with x to 1e11 -- come in two
+ *     FLAVOURS (rzo_math_flavour, at the end of this file):
+ *       1 (the default, and the product's since round 5): Mesa llvmpipe's,
+ *         replayed bit for bit -- the implementation RayZen's shader was RUN
+ *         on here, so that oracle, product and the reference's own frames
+ *         agree pixel by pixel at every bounce budget (tests/test_glref.py);
+ *       0 (rounds 1-4): computed in binary64 from + - * / sqrt fma floor rint
+ *         only and rounded once to binary32 (fdlibm k_sin / k_cos / e_acos
+ *         coefficients, 3-term Cody-Waite split of pi/2 applied with fma):
+ *         correctly rounded.  Agrees with the shader wherever no random
+ *         number is drawn.
  */
 #ifndef RZ_ORACLE_MATH_H
 #define RZ_ORACLE_MATH_H
@@ -141,12 +143,12 @@ static inline float rzo_acos_pinned(float xf) {
 }
 
 /* ---------------------------------------------------------------------------------------------------------------------
- * MATH FLAVOUR 1: sin / cos / acos as the GL implementation computes them that runs RayZen's own shader in oracle/glref
- * (Mesa 23.2 llvmpipe on an x86-64 with FMA).  FOR ONE PURPOSE: with it, the oracle and RayZen's shader draw the SAME
- * random numbers (FS:188-190: fract(sin(x) * 43758.5453), x up to 1e11 -- where an implementation's range reduction decides
- * every bit), so frames of any bounce budget can be compared pixel by pixel (tests/test_glref.py), not only in
- * distribution.  The default flavour 0 -- the pinned definitions above -- is what the product implements and what every
- * parity test uses; the two flavours differ in these three functions and nowhere else.
+ * MATH FLAVOUR 1 (the default; the product's RZ_MATH_FLAVOUR=1): sin / cos / acos as the GL implementation computes them that
+ * runs RayZen's own shader in oracle/glref (Mesa 23.2 llvmpipe on an x86-64 with FMA).  With it the oracle, the product and
+ * RayZen's shader draw the SAME random numbers (FS:188-190: fract(sin(x) * 43758.5453), x up to 1e11 -- where an
+ * implementation's range reduction decides every bit), so frames of any bounce budget agree pixel by pixel
+ * (tests/test_glref.py), not only in distribution.  Flavour 0 -- the binary64 definitions above, rounds 1-4's specification and
+ * still a build option of the product -- differs in these three functions and nowhere else.
  *   sin, cos: gallivm's lp_build_sin_or_cos -- Cephes' sinf / cosf as in J. Pommier's sse_mathfun: octant j = (trunc(|x| * 4/pi)
  *     + 1) & ~1 (x86 cvttps2dq: 0x80000000 out of range), three-constant Cody-Waite reduction and both polynomials with
  *     FUSED multiply-adds (llvm.fmuladd on a machine with FMA), the result clamped to [-1, 1];

@@ -109,6 +109,8 @@ def lib():
         L.rzo_mat4_inverse.argtypes = [C.c_void_p, C.c_void_p]
         L.rzo_load_obj.restype = C.c_int
         L.rzo_load_obj.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int]
+        if os.environ.get("RZO_MATH_FLAVOUR"):         # A/B aid: the process-wide default of rz_oracle_math.h's flavour
+            L.rzo_set_math_flavour(int(os.environ["RZO_MATH_FLAVOUR"]))
         _lib = L
     return _lib
 
@@ -166,8 +168,9 @@ def render(scene, frame, accum=None, ior_state=None, crop=None, nthreads=1, want
 
 
 class math_flavour:
-    """with rzo.math_flavour(1): ...  -- sin / cos / acos as Mesa llvmpipe computes them (rz_oracle_math.h), for comparisons
-    with frames of RayZen's own shader (tests/test_glref.py).  Everything else uses flavour 0, the pinned built-ins."""
+    """with rzo.math_flavour(0): ...  -- which sin / cos / acos the oracle evaluates inside the block (rz_oracle_math.h): 1 = Mesa
+    llvmpipe's (the default and the product's), 0 = rounds 1-4's binary64 ones.  tests/helpers.py sets the process default to
+    the loaded product library's (rz_math_flavour())."""
 
     def __init__(self, flavour):
         self.flavour = int(flavour)

@@ -20,7 +20,7 @@ HIP_SYMBOLS = (
     "rz_group_rccl_version", "rz_group_unique_id", "rz_group_create", "rz_group_create_rank", "rz_group_destroy",
     "rz_group_last_error", "rz_group_size", "rz_group_local_count", "rz_group_rank", "rz_group_ctx", "rz_group_upload",
     "rz_group_update", "rz_group_set_frame", "rz_group_render", "rz_group_reduce", "rz_group_sync", "rz_group_read_frame",
-    "rz_group_frame_device_ptr", "rz_group_last_reduce_ms", "rz_group_transport", "rz_group_set_transport", "rz_abi_version", "rz_debug_poke_backstop",
+    "rz_group_frame_device_ptr", "rz_group_last_reduce_ms", "rz_group_transport", "rz_group_set_transport", "rz_abi_version", "rz_debug_poke_backstop", "rz_math_flavour",
 )
 ABI_VERSION = 5         # RZ_ABI_VERSION of the include/rayzen_hip.h this file mirrors
 # the symbols include/rayzen_host.h declares
@@ -146,7 +146,7 @@ def hip():
         for name, res, args in (("rz_group_last_reduce_ms", i, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
                                 ("rz_group_transport", C.c_char_p, [vp]),
                                 ("rz_group_set_transport", i, [vp, C.c_char_p]),
-                                ("rz_abi_version", i, []), ("rz_debug_poke_backstop", i, [vp, C.c_uint])):
+                                ("rz_abi_version", i, []), ("rz_debug_poke_backstop", i, [vp, C.c_uint]), ("rz_math_flavour", i, [])):
             try:
                 fn = getattr(L, name)
                 fn.restype, fn.argtypes = res, args

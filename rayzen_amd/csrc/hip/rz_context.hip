@@ -24,6 +24,7 @@
 
 #include "rayzen_hip.h"
 #include "rz_internal.h"
+#include "rz_device_math.h"      // RZ_MATH_FLAVOUR (rz_math_flavour())
 
 
 using namespace rz;
@@ -910,6 +911,7 @@ static const char rz_stamp[] = "RZSRCHASH:" RZ_SOURCE_HASH;
 const char* rz_source_hash(void) { return rz_stamp + 10; }
 const char* rz_version(void) { return "rayzen_hip 0.5 (gfx950)"; }
 int rz_abi_version(void) { return RZ_ABI_VERSION; }
+int rz_math_flavour(void) { return RZ_MATH_FLAVOUR; }
 
 int rz_device_count(void) {
     int n = 0;

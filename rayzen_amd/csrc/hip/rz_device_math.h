@@ -11,13 +11,11 @@
 //     -fhip-fp32-correctly-rounded-divide-sqrt);
 //   * GLSL min/max/clamp = v_min_f32 / v_max_f32 (IEEE minNum/maxNum: the
 //     non-NaN operand wins), which is also what a GPU running FS does;
-//   * sin/cos/acos, which GLSL leaves to the driver, are defined here once
-//     and for all: binary64 evaluation built only from fma, mul, add, div,
-//     sqrt, rint and floor (each exactly specified by IEEE-754), rounded once
-//     to binary32.  Cody-Waite reduction by pi/2 in three fma steps, then the
-//     classic fdlibm minimax polynomials (k_sin.c / k_cos.c / e_acos.c
-//     coefficients).  v_fma_f64 runs at half the f32 rate on CDNA4 and these
-//     are a few dozen operations per bounce: noise next to BVH traversal.
+//   * sin/cos/acos, which GLSL leaves to the driver, are those of the driver
+//     RayZen's own shader was run on for this project (Mesa llvmpipe; see
+//     "sin / cos / acos" below): with them this renderer draws the random
+//     numbers that run of the reference drew.  Rounds 1-4's definition
+//     (binary64, correctly rounded) stays behind -DRZ_MATH_FLAVOUR=0.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -185,6 +183,96 @@ __device__ __forceinline__ v3 normalize(v3 a) {
 }
 
 // ---- sin / cos / acos -----------------------------------------------------
+// GLSL leaves these three to the implementation; RZ_MATH_FLAVOUR chooses which implementation the product IS:
+//   1: Mesa llvmpipe's -- the OpenGL implementation RayZen's own shader was RUN on for this project (the test harness beside the
+//      oracle; tests/test_glref.py): sin / cos = Cephes' single-precision routine as in sse_mathfun / gallivm (octant
+//      j = (trunc(|x| 4/pi) + 1) & ~1 with x86's out-of-range conversion, three-constant Cody-Waite reduction and both polynomials
+//      with FUSED multiply-adds, result clamped to [-1, 1]), acos = Mesa's GLSL polynomial in unfused binary32.  With it the
+//      renderer draws the random numbers RayZen's shader draws on that implementation (FS:188-190: fract(sin(x) * 43758.5453),
+//      x to 1e11 -- the range reduction decides every bit), so its frames can be held against the reference's own frames pixel
+//      by pixel at every bounce budget.  ~25 binary32 instructions per sin.
+//      THE DEFAULT since round 5.  Same box, against flavour 0 (profiles/r05_flavour/): C2 10.31 -> 10.10 ms although the frame
+//      does 2 % more traversal work with these random numbers, C4 7.41 -> 6.78, c2g 21.3 -> 18.7, RayZen's own frame 0.310 ->
+//      0.251 ms, c2close +0.8 %, glassbunny +1.7 %.
+//   0: rounds 1-4's definition: binary64 evaluation (Cody-Waite by pi/2 in three fma steps, fdlibm's k_sin / k_cos / e_acos
+//      polynomials) rounded once to binary32 -- correctly rounded, ~77 binary64 instructions per sin at half rate.  Still
+//      built by -DRZ_MATH_FLAVOUR=0 (its hemisphere draw then goes behind a call again: rz_path.h) and tested the same way: the oracle holds
+//      both definitions and the suite asks the loaded library which one it is (rz_math_flavour()).
+// The reduction + both polynomials (sincos_core, ~25 instructions, five values out) sit behind ONE call shared by sin_ / cos_ /
+// sincos_ (RZ_SINCOS_NOINLINE): inlined at its seven sites it cost the opaque kernels 1-3 % (C2 10.37 vs 10.10 ms, C3 39.8 vs
+// 38.5), the same effect as every other piece of cold, stateless code moved out of the one big function (profiles/r05_regs/).
+#ifndef RZ_MATH_FLAVOUR
+#define RZ_MATH_FLAVOUR 1
+#endif
+#if RZ_MATH_FLAVOUR == 1
+struct SinCosF { float xr, z, ps, pc; unsigned j; };
+#ifndef RZ_SINCOS_NOINLINE
+#define RZ_SINCOS_NOINLINE 1
+#endif
+#if RZ_SINCOS_NOINLINE
+static __device__ __attribute__((noinline)) SinCosF sincos_core(float x) {
+#else
+__device__ __forceinline__ SinCosF sincos_core(float x) {
+#endif      // x >= 0 (the callers pass |x|)
+    const float scale = x * 1.27323954473516f;
+    // cvttps2dq: truncation, and 0x80000000 for everything out of range (v_cvt_i32_f32 would saturate)
+    const int jt = (scale < 2147483648.0f) ? (int)scale : (int)0x80000000;
+    SinCosF o;
+    o.j = ((unsigned)jt + 1u) & ~1u;
+    const float y = (float)(int)o.j;
+    float xr = __builtin_fmaf(y, -0.78515625f, x);
+    xr = __builtin_fmaf(y, -2.4187564849853515625e-4f, xr);
+    xr = __builtin_fmaf(y, -3.77489497744594108e-8f, xr);
+    const float z = xr * xr;
+    float c = __builtin_fmaf(z, 2.443315711809948E-005f, -1.388731625493765E-003f);
+    c = __builtin_fmaf(c, z, 4.166664568298827E-002f);
+    c = c * z;
+    c = c * z;
+    c = c - z * 0.5f;
+    c = c + 1.0f;
+    float sn = __builtin_fmaf(z, -1.9515295891E-4f, 8.3321608736E-3f);
+    sn = __builtin_fmaf(sn, z, -1.6666654611E-1f);
+    sn = sn * z;
+    sn = __builtin_fmaf(sn, xr, xr);
+    o.xr = xr; o.z = z; o.ps = sn; o.pc = c;
+    return o;
+}
+__device__ __forceinline__ float sincos_finish(float v, unsigned signbit) {
+    float r = __uint_as_float(__float_as_uint(v) ^ signbit);
+    r = (r < 1.0f) ? r : 1.0f;          // (x86 minps / maxps: a NaN -- x^2 overflowed -- yields the bound)
+    r = (r > -1.0f) ? r : -1.0f;
+    return r;
+}
+__device__ __forceinline__ float sin_(float x) {
+    const SinCosF t = sincos_core(__builtin_fabsf(x));
+    const unsigned sign = (__float_as_uint(x) & 0x80000000u) ^ ((t.j & 4u) << 29);
+    return sincos_finish((t.j & 2u) == 0u ? t.ps : t.pc, sign);
+}
+__device__ __forceinline__ float cos_(float x) {
+    const SinCosF t = sincos_core(__builtin_fabsf(x));
+    const unsigned e = t.j - 2u;
+    return sincos_finish((e & 2u) == 0u ? t.ps : t.pc, ((~e) & 4u) << 29);
+}
+// sin and cos of the same angle from one reduction and one pair of polynomials: the bits of sin_(x) and cos_(x).
+__device__ __forceinline__ void sincos_(float x, float& s, float& c) {
+    const SinCosF t = sincos_core(__builtin_fabsf(x));
+    const unsigned e = t.j - 2u;
+    s = sincos_finish((t.j & 2u) == 0u ? t.ps : t.pc, (__float_as_uint(x) & 0x80000000u) ^ ((t.j & 4u) << 29));
+    c = sincos_finish((e & 2u) == 0u ? t.ps : t.pc, ((~e) & 4u) << 29);
+}
+__device__ __forceinline__ float acos_(float x) {
+    const float PIO2 = 1.57079632679489661923f, PIO4M1 = 0.78539816339744830962f - 1.0f;
+    const float ax = __builtin_fabsf(x);
+    float e = 0.08132463f + ax * -0.02363318f;
+    e = PIO4M1 + ax * e;
+    e = PIO2 + ax * e;
+    const float sgn = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+    const float t = 1.0f - ax;
+    const float rt = (rz_ballot(!sqrt_mid_ok(t)) == 0ull) ? sqrt_mid(t) : sqrt_ieee(t);
+    const float as = sgn * (PIO2 - rt * e);
+    return PIO2 - as;
+}
+#else
 // A binary64 literal cannot be an inline operand on gfx950, so hipcc materialises each one in a register pair -- and,
 // left alone, hoists all ~24 of them out of the sample loop and keeps them in VGPRs across the whole BVH walk
 // (measured: the fused kernel wanted 193 VGPRs where trace and shading need 82 and 84 on their own).  KD() pins a
@@ -273,8 +361,14 @@ __device__ __forceinline__ float acos_(float xf) {
     return (float)res;
 }
 
+#endif      // RZ_MATH_FLAVOUR
+
 // FS:188-190
+#if defined(RZ_RAND_NOINLINE) && RZ_RAND_NOINLINE
+static __device__ __attribute__((noinline)) float rand_(v2 uv) {
+#else
 __device__ __forceinline__ float rand_(v2 uv) {
+#endif
     float d = uv.x * 12.9898f + uv.y * 78.233f;
     return fract_(sin_(d) * 43758.5453f);
 }

@@ -121,8 +121,10 @@ __device__ __forceinline__ v3 hemisphere_local(v2 seed) {
 // inlined it shares the path's register allocation -- behind a call it has its own frame, the kernel is 2 400 instructions
 // shorter and C2 1.8 % faster (c2close -0.9 %, C5 -1.5 %).  The transparent kernels keep it inline: there the call's save /
 // restore lands on paths that are live across it more often (c2g +2.2 %, RayZen's scene at 64 spp +4.2 %).  Same operations either way.
+// (Flavour 1's draw is ~250 binary32 instructions around calls of the shared sin / cos core: inline everywhere -- behind a call
+//  of its own C2 ran 10.78 ms against 10.10.)
 #ifndef RZ_HEMI_OUT_OF_LINE
-#define RZ_HEMI_OUT_OF_LINE 1
+#define RZ_HEMI_OUT_OF_LINE (RZ_MATH_FLAVOUR == 0)
 #endif
 static __device__ __attribute__((noinline)) v3 hemisphere_local_call(v2 seed) { return hemisphere_local(seed); }
 __device__ __forceinline__ v3 hemisphere_world(v3 normal, v3 dir) {

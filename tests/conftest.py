@@ -31,6 +31,8 @@ def _built():
         print(f"[conftest] RAYZEN_HIP_SO override: testing {_lib.HIP_SO} (source hash {loaded[:16]}, tree {tree[:16]})", file=sys.stderr)
     else:
         assert loaded == tree, f"{_lib.HIP_SO} was built from other sources ({loaded[:16]}) than this tree ({tree[:16]})"
+    from helpers import sync_oracle_flavour
+    sync_oracle_flavour()
     yield
 
 

@@ -3,10 +3,11 @@
 
     python tests/golden/make_golden.py
 
-The reference cannot produce them (its renderer needs an OpenGL context, its host code needs GLM; neither
-exists here -- DESIGN.md "Oracle"), and it ships no golden vectors of its own.  These files therefore pin the
-ORACLE: any drift of its output across compilers, machines or edits shows up as a diff against them, on the
-CPU suite here and (through the HIP path) on the GPU box.  Inputs are fully synthetic (rayzen_amd/scene.py).
+These files pin the ORACLE against itself: any drift of its output across compilers, machines or edits shows up as
+a diff against them, on the CPU suite here and (through the HIP path) on the GPU box -- accumulation buffers and
+algorithmic tallies at sizes the shader-made fixtures (tests/golden/make_glref.py: frames of RayZen's own shader,
+which pin the oracle against the REFERENCE) do not cover.  Rendered with the math flavour of the product library
+in the tree (1 since round 5: tests/helpers.py).  Inputs are fully synthetic (rayzen_amd/scene.py).
 """
 import os
 import sys

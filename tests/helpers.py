@@ -5,6 +5,21 @@ from oracle import rzo
 from rayzen_amd import scene as S
 
 
+def sync_oracle_flavour():
+    """The oracle evaluates sin / cos / acos as the LOADED product library does (rz_math_flavour(): a compile-time choice of
+    rz_device_math.h; oracle/rz_oracle_math.h holds both definitions).  Called once per process by the suite's session fixture,
+    __graft_entry__.smoke() and bench.py's oracle legs.  Returns the flavour."""
+    global _FLAVOUR
+    from rayzen_amd import _lib
+    L = _lib.hip()
+    _FLAVOUR = int(L.rz_math_flavour()) if hasattr(L, "rz_math_flavour") else 0
+    rzo.lib().rzo_set_math_flavour(_FLAVOUR)
+    return _FLAVOUR
+
+
+_FLAVOUR = None
+
+
 def oracle_scene(scene):
     a = scene.arrays
     return rzo.Scene(a[S.BIND_TRIANGLES], a[S.BIND_MATERIALS], a[S.BIND_LIGHTS], a[S.BIND_TLAS_NODES],
@@ -12,6 +27,8 @@ def oracle_scene(scene):
 
 
 def oracle_frame(scene, width, height, spp, bounces, sample_base=0, num_lights=None):
+    if _FLAVOUR is None:        # (first oracle frame of a process that did not come through the suite's fixture: a child script)
+        sync_oracle_flavour()
     cam = scene.camera
     nl = len(scene.lights) if num_lights is None else num_lights
     return rzo.make_frame(width, height, cam.inv_view, cam.inv_proj, cam.position, nl, bounces, spp, sample_base)

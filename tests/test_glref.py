@@ -86,10 +86,11 @@ def compare(got, want, render, what, same_random_numbers):
     return msg
 
 
-def oracle_fragcolor(sc, r, flavour=0):
+def oracle_fragcolor(sc, r, flavour=None):
+    """flavour None: the one the suite runs in -- the loaded product library's (conftest: sync_oracle_flavour)."""
     fr = oracle_frame(sc, r["W"], r["H"], r["spp"], r["budget"])
     osc = oracle_scene(sc)
-    with rzo.math_flavour(flavour):
+    with rzo.math_flavour(rzo.lib().rzo_get_math_flavour() if flavour is None else flavour):
         acc = rzo.render(osc, fr, nthreads=8)
     rgb, _ = rzo.present(osc, acc, sc.camera.view, sc.camera.proj, len(sc.lights), **{k: r[k] for k in OVERLAY_KEYS if k in r})
     return rgb
@@ -122,8 +123,8 @@ def test_flavour_1_is_llvmpipes_sin_cos_acos():
     for got, key in ((s, "sin"), (c, "cos"), (a, "acos")):
         assert (got.view(np.uint32) == z[key].view(np.uint32)).all(), key
     assert np.isfinite(h).all()
-    assert rzo.lib().rzo_get_math_flavour() == 0
-    s0 = np.array([L.rzo_sin_f(float(v)) for v in x], np.float32)
+    with rzo.math_flavour(0):
+        s0 = np.array([L.rzo_sin_f(float(v)) for v in x], np.float32)
     small, big = np.abs(x) < 1e5, np.abs(x) > 1e8
     assert np.abs(s0[small].astype(np.float64) - z["sin"][small]).max() <= 1.2e-7
     assert np.abs(s0[big].astype(np.float64) - z["sin"][big]).max() > 1.0
@@ -139,7 +140,7 @@ def test_oracle_with_llvmpipes_built_ins_matches_the_reference_shader_pixel_by_p
 @pytest.mark.parametrize("name,k", CASES)
 def test_oracle_matches_the_reference_shader(name, k):
     sc, renders, outs, _ = load(name)
-    print(compare(oracle_fragcolor(sc, renders[k]), outs[k], renders[k], f"oracle vs RayZen's shader, {name}[{k}]", False))
+    print(compare(oracle_fragcolor(sc, renders[k], flavour=0), outs[k], renders[k], f"oracle[flavour 0] vs RayZen's shader, {name}[{k}]", False))
 
 
 @pytest.mark.gpu
@@ -158,7 +159,8 @@ def test_hip_matches_the_reference_shader(name, k):
         rgb, _ = R.present(**{x: r[x] for x in OVERLAY_KEYS if x in r})
     finally:
         R.close()
-    print(compare(rgb, outs[k], r, f"HIP vs RayZen's shader, {name}[{k}]", False))
+    flavour = rzo.lib().rzo_get_math_flavour()          # (the loaded library's: conftest)
+    print(compare(rgb, outs[k], r, f"HIP[flavour {flavour}] vs RayZen's shader, {name}[{k}]", flavour == 1))
     ref = oracle_fragcolor(sc, r)
     assert (rgb.view(np.uint32) == ref.view(np.uint32)).all(), "HIP and oracle differ on a fixture scene"
 
@@ -206,7 +208,7 @@ def test_random_scenes_against_the_live_shader(seed):
     want = np.ascontiguousarray(img[..., :3])
     compare(oracle_fragcolor(sc, r, flavour=1), want, r, f"oracle[flavour 1] vs the live shader, seed {seed}", True)
     if b <= 2:
-        compare(oracle_fragcolor(sc, r), want, r, f"oracle vs the live shader, seed {seed}", False)
+        compare(oracle_fragcolor(sc, r, flavour=0), want, r, f"oracle[flavour 0] vs the live shader, seed {seed}", False)
 
 
 @pytest.mark.parametrize("config", ["rayzen 800x600", "bench 1920x1080"])

@@ -1,8 +1,10 @@
-"""The pinned built-ins of oracle/rz_oracle_math.h: accuracy (they are meant to be sin/cos/acos, not just
-deterministic), known answers, and the GLSL helper semantics."""
+"""The built-ins of oracle/rz_oracle_math.h: accuracy (they are meant to be sin/cos/acos, not just deterministic), known
+answers, and the GLSL helper semantics.  Flavour 0 = rounds 1-4's binary64 definitions (correctly rounded); flavour 1 = Mesa
+llvmpipe's, the default since round 5 -- pinned bit for bit against llvmpipe's own tables in tests/test_glref.py."""
 import math
 
 import numpy as np
+import pytest
 
 from oracle import rzo
 
@@ -15,7 +17,19 @@ def _ulp_err(got, want):
     return abs(float(got) - want) / float(np.spacing(np.abs(want32)) or 1e-45)
 
 
-def test_sin_cos_match_correctly_rounded_libm_over_the_rng_argument_range():
+@pytest.fixture
+def flavour0():
+    with rzo.math_flavour(0):
+        yield
+
+
+@pytest.fixture
+def flavour1():
+    with rzo.math_flavour(1):
+        yield
+
+
+def test_sin_cos_match_correctly_rounded_libm_over_the_rng_argument_range(flavour0):
     L = rzo.lib()
     rng = np.random.default_rng(1234)
     xs = np.concatenate([rng.uniform(-8, 8, 3000), rng.uniform(-3e5, 3e5, 3000), rng.uniform(-4e10, 4e10, 3000),
@@ -31,7 +45,7 @@ def test_sin_cos_match_correctly_rounded_libm_over_the_rng_argument_range():
     assert exact >= 2 * len(xs) - 2                  # ... and correctly rounded essentially always
 
 
-def test_acos_accuracy_and_endpoints():
+def test_acos_accuracy_and_endpoints(flavour0):
     L = rzo.lib()
     rng = np.random.default_rng(5)
     for x in np.concatenate([rng.uniform(-1, 1, 4000), [0.0, 0.5, -0.5, 0.4999999, 0.99999994]]).astype(np.float32):
@@ -41,9 +55,11 @@ def test_acos_accuracy_and_endpoints():
     assert math.isnan(L.rzo_acos_f(float("nan")))
 
 
-def test_rand_is_fract_sin_dot():
-    """FS:188-190 with the pinned sin: recompute in numpy float32, operation by operation."""
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_rand_is_fract_sin_dot(flavour):
+    """FS:188-190 with the flavour's sin: recompute in numpy float32, operation by operation."""
     L = rzo.lib()
+    L.rzo_set_math_flavour(flavour)
     rng = np.random.default_rng(2)
     for _ in range(500):
         x, y = np.float32(rng.uniform(0, 3000)), np.float32(rng.uniform(0, 3000))
@@ -53,14 +69,30 @@ def test_rand_is_fract_sin_dot():
         want = np.float32(p - np.floor(p))
         got = np.float32(L.rzo_rand_f(float(x), float(y)))
         assert got == want and 0.0 <= got < 1.0
+    L.rzo_set_math_flavour(1)
 
 
-def test_rand_known_answers():
+def test_rand_known_answers(flavour0):
     """Values committed from this oracle (regression pin; the reference publishes none)."""
     L = rzo.lib()
     assert L.rzo_rand_f(0.3, 0.7) == 0.08203125
     assert L.rzo_rand_f(1234.5, 6789.1) == 0.755859375
     assert L.rzo_rand_f(0.0, 0.0) == 0.0
+
+
+def test_llvmpipe_flavour_is_an_accurate_sine_where_sines_are_expected(flavour1):
+    """Flavour 1 is Cephes' single-precision routine: within an ulp or two of the true value for |x| < 1e4 (the camera jitter's
+    arguments), and still a deterministic function -- if no longer a sine -- at the hash's 1e8 ... 1e11."""
+    L = rzo.lib()
+    rng = np.random.default_rng(77)
+    for x in np.concatenate([rng.uniform(-8, 8, 2000), rng.uniform(-1e4, 1e4, 2000)]).astype(np.float32):
+        assert abs(L.rzo_sin_f(float(x)) - math.sin(float(x))) <= 1.3e-7
+        assert abs(L.rzo_cos_f(float(x)) - math.cos(float(x))) <= 1.3e-7
+    for x in rng.uniform(-1, 1, 2000).astype(np.float32):
+        assert abs(L.rzo_acos_f(float(x)) - math.acos(float(x))) <= 1.7e-4      # Mesa's polynomial
+    assert L.rzo_acos_f(1.0) == 0.0 and L.rzo_rand_f(0.0, 0.0) == 0.0
+    for x in (3.0e8, 2.5e9, 7.7e10):
+        assert -1.0 <= L.rzo_sin_f(x) <= 1.0 and L.rzo_sin_f(x) == L.rzo_sin_f(x)
 
 
 def test_hemisphere_direction_is_unit_and_on_the_normal_side():
