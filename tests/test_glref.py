@@ -10,19 +10,21 @@ the shader's hash is `fract(sin(x) * 43758.5453)` with x up to 1e11, where the r
 any two implementations draw DIFFERENT random numbers from the third path segment on (the first two consume none: FS:696
 seeds bounce 0 with (0, 0)).  So:
 
-  (1) MATH FLAVOUR 1 of the oracle (oracle/rz_oracle_math.h) evaluates sin / cos / acos exactly as llvmpipe does -- shown
-      bit for bit against llvmpipe's own tables (test_flavour_1_is_llvmpipes_sin_cos_acos) -- and nothing else differently.
+  (1) MATH FLAVOUR 1 (oracle/rz_oracle_math.h; since round 5 also what the PRODUCT is compiled with: rz_device_math.h,
+      rz_math_flavour()) evaluates sin / cos / acos exactly as llvmpipe does -- shown bit for bit against llvmpipe's own tables
+      (test_flavour_1_is_llvmpipes_sin_cos_acos) -- and nothing else differently.
       With it the oracle and RayZen's shader draw the same numbers, and EVERY frame, at any budget and sample count, must
       agree pixel by pixel: measured <= 1.3e-5 on RayZen's own scene at its own budget 5, half the pixels bit-identical, a few
       pixels per 10 000 beyond 1e-4 where a comparison sits on a knife edge or a long mirror chain amplifies the last bit.
       This is the test that pins the oracle's reading of the whole path loop: traversal, lighting, shadows through glass,
       refraction / total internal reflection / currentIor, mirror-or-diffuse choice, hemisphere draw, Russian roulette, the
       sum over samples, resolve and overlays.
-  (2) FLAVOUR 0 -- the pinned built-ins, the ones the product implements and every parity test uses -- differs from (1) in those
-      three functions only.  Against the shader it must agree to rounding wherever no random number is consumed (budgets
-      1-2: every pixel within 1e-4) and, at higher budgets, wherever a path ends within two segments (>= 85 % of the pixels);
-      the rest are equally valid samples drawn with another generator.  The HIP path is held to the same, and to the oracle
-      bit for bit.
+  (2) FLAVOUR 0 -- rounds 1-4's binary64, correctly rounded built-ins; the product's -DRZ_MATH_FLAVOUR=0 build -- differs from (1)
+      in those three functions only.  Against the shader it must agree to rounding wherever no random number is consumed
+      (budgets 1-2: every pixel within 1e-4) and, at higher budgets, wherever a path ends within two segments (>= 85 % of the
+      pixels); the rest are equally valid samples drawn with another generator.
+  The HIP path (GPU suite) is held to (1) or (2) according to the flavour of the library that is loaded -- the default build: (1),
+  every frame against the reference's own, pixel by pixel -- and to the oracle in that flavour bit for bit.
 """
 import json
 import os
