@@ -57,23 +57,31 @@ struct Path {
     int gflag;          // pooled paths of a transparent scene (GMODE 2): 1 = P.ior is the value the sequential shader would hand this sample (it may scatter at glass)
 };
 
-// FS:204-212 + FS:688-692
+// FS:204-212 + FS:688-692: the sample's seed and its camera ray direction from (uv, fragCoord.x + y, sample index).
+struct CameraRay { v2 seed; v3 d; };
+__device__ __forceinline__ CameraRay camera_ray(const float* __restrict__ invProj, const float* __restrict__ invView, const v2 uv, const float fragSum, const int samp) {
+    CameraRay r;
+    const float sf = ((fragSum + (float)samp) + 1.0f);
+    r.seed.x = uv.x * sf;
+    r.seed.y = uv.y * sf;
+    v2 s1; s1.x = r.seed.x + 1.0f; s1.y = r.seed.y + 1.0f;
+    const float jx = rand_(r.seed) * 0.00002f, jy = rand_(s1) * 0.00002f;
+    const float ux = uv.x + jx, uy = uv.y + jy;
+    const float cx = ux * 2.0f - 1.0f, cy = uy * 2.0f - 1.0f;
+    const float* ip = invProj;
+    const float ex = ((ip[0] * cx + ip[4] * cy) + ip[8] * -1.0f) + ip[12] * 1.0f;
+    const float ey = ((ip[1] * cx + ip[5] * cy) + ip[9] * -1.0f) + ip[13] * 1.0f;
+    const v3 world = xform_dir(invView, mk3(ex, ey, -1.0f));
+    r.d = normalize(world);
+    return r;
+}
 template <bool COUNT>
 __device__ __forceinline__ void begin_sample(const KParams& K, Path& P, Tally& c) {
     if (COUNT) c.samples += 1;
-    const float sf = ((P.fragSum + (float)P.samp) + 1.0f);
-    P.seed.x = P.uv.x * sf;
-    P.seed.y = P.uv.y * sf;
-    v2 s1; s1.x = P.seed.x + 1.0f; s1.y = P.seed.y + 1.0f;
-    const float jx = rand_(P.seed) * 0.00002f, jy = rand_(s1) * 0.00002f;
-    const float ux = P.uv.x + jx, uy = P.uv.y + jy;
-    const float cx = ux * 2.0f - 1.0f, cy = uy * 2.0f - 1.0f;
-    const float* ip = K.invProj;
-    const float ex = ((ip[0] * cx + ip[4] * cy) + ip[8] * -1.0f) + ip[12] * 1.0f;
-    const float ey = ((ip[1] * cx + ip[5] * cy) + ip[9] * -1.0f) + ip[13] * 1.0f;
-    const v3 world = xform_dir(K.invView, mk3(ex, ey, -1.0f));
+    const CameraRay r = camera_ray(K.invProj, K.invView, P.uv, P.fragSum, P.samp);
+    P.seed = r.seed;
     P.o = mk3(K.camPos[0], K.camPos[1], K.camPos[2]);
-    P.d = normalize(world);
+    P.d = r.d;
     P.throughput = mk3(1.0f, 1.0f, 1.0f);
     P.bounce = 0;
     P.mode = MODE_SEGMENT;
@@ -126,6 +134,9 @@ __device__ __forceinline__ v3 hemisphere_local(v2 seed) {
 #ifndef RZ_HEMI_OUT_OF_LINE
 #define RZ_HEMI_OUT_OF_LINE (RZ_MATH_FLAVOUR == 0)
 #endif
+#ifndef RZ_HEMI_OUT_OF_LINE_GLASS
+#define RZ_HEMI_OUT_OF_LINE_GLASS 0
+#endif
 static __device__ __attribute__((noinline)) v3 hemisphere_local_call(v2 seed) { return hemisphere_local(seed); }
 __device__ __forceinline__ v3 hemisphere_world(v3 normal, v3 dir) {
     const v3 up = (__builtin_fabsf(normal.y) < 0.99f) ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
@@ -141,7 +152,7 @@ template <bool GLASS>
 __device__ __forceinline__ v3 random_hemisphere_direction(const KParams& K, v3 normal, v2 seed) {
     const bool zero = __float_as_uint(seed.x) == 0u && __float_as_uint(seed.y) == 0u;
     v3 dir = mk3(K.hemi0[0], K.hemi0[1], K.hemi0[2]);
-    if (!zero) dir = (RZ_HEMI_OUT_OF_LINE && !GLASS) ? hemisphere_local_call(seed) : hemisphere_local(seed);
+    if (!zero) dir = ((RZ_HEMI_OUT_OF_LINE && !GLASS) || (RZ_HEMI_OUT_OF_LINE_GLASS && GLASS)) ? hemisphere_local_call(seed) : hemisphere_local(seed);
     return hemisphere_world(normal, dir);
 }
 
@@ -174,21 +185,23 @@ __device__ __forceinline__ void start_light(const KParams& K, Path& P, Tally& c)
     RZ_T1(c, 5);
 }
 
-// The light P.li is visible with P.vis: add its term (FS:589-607 / FS:636-659).
+// The light `li` is visible with `vis` from the surface point (hp, hn, material hmat) along lightDir: its term (FS:589-607 /
+// FS:636-659), or false where the shader returns without one.  Values in, values out -- no path state by reference -- so that the
+// same code can sit behind a call (RZ_SHADE_NOINLINE, measured in profiles/r05_flavour/).
 template <bool GLASS>
-__device__ __forceinline__ void shade_light(const KParams& K, Path& P) {
-    const DevLight L = K.lights[P.li];
-    const DevMaterial M = K.materials[P.hmat];
-    const v3 lightDir = P.d;
-    const v3 normal = P.hn;
-    const v3 viewDir = normalize(mk3(K.camPos[0], K.camPos[1], K.camPos[2]) - P.hp);   // FS:714
+__device__ __forceinline__ bool shade_term(const DevLight* __restrict__ lights, const DevMaterial* __restrict__ materials, const v3 cam,
+                                           const v3 hp, const v3 normal, const v3 lightDir, const float maxDist, const float vis,
+                                           const int li, const int hmat, v3& term) {
+    const DevLight L = lights[li];
+    const DevMaterial M = materials[hmat];
+    const v3 viewDir = normalize(cam - hp);   // FS:714
     const v3 albedo = mk3(M.albedo[0], M.albedo[1], M.albedo[2]);
     const v3 lcolor = mk3(L.color[0], L.color[1], L.color[2]);
-    float attenuation = (L.posdir[3] == 1.0f) ? L.power / (P.maxDist * P.maxDist) : L.power;
-    attenuation *= P.vis;
+    float attenuation = (L.posdir[3] == 1.0f) ? L.power / (maxDist * maxDist) : L.power;
+    attenuation *= vis;
     if (GLASS && M.transparency > 0.0f) {
         const float NdotL = fmax_(dot(normal, lightDir), 0.0f);
-        if (NdotL <= 0.0f) return;
+        if (NdotL <= 0.0f) return false;
         const float f0 = pow2_((1.0f - M.ior) / (1.0f + M.ior));
         const v3 H = normalize(lightDir + viewDir);
         const float NdotH = fmax_(dot(normal, H), 0.0f);
@@ -205,7 +218,7 @@ __device__ __forceinline__ void shade_light(const KParams& K, Path& P) {
         const float Gl = NdotL / ((NdotL * (1.0f - k) + k) + 1e-6f);
         const float denom = fmax_((4.0f * NdotL) * NdotV, 1e-4f);
         const v3 spec = div3(((F * D) * Gv) * Gl, denom);
-        P.lacc = P.lacc + ((spec * lcolor) * attenuation) * NdotL;
+        term = ((spec * lcolor) * attenuation) * NdotL;
     } else {
         const v3 F0 = mk3(mix_(0.04f, albedo.x, M.metallic), mix_(0.04f, albedo.y, M.metallic),
                           mix_(0.04f, albedo.z, M.metallic));
@@ -226,7 +239,34 @@ __device__ __forceinline__ void shade_light(const KParams& K, Path& P) {
         const v3 oneMinusF = mk3(1.0f - F.x, 1.0f - F.y, 1.0f - F.z);
         const v3 diffuse = div3((oneMinusF * albedo) * NdotL, 3.14159f);
         const v3 t = ((diffuse + specular) * lcolor) * attenuation;
-        P.lacc = P.lacc + mk3(fmax_(0.0f, t.x), fmax_(0.0f, t.y), fmax_(0.0f, t.z));
+        term = mk3(fmax_(0.0f, t.x), fmax_(0.0f, t.y), fmax_(0.0f, t.z));
+    }
+    return true;
+}
+// Behind a call the BRDF term costs the opaque kernels 1.6-1.8 % (C2 10.12 -> 10.30 ms, C3 38.5 -> 39.1) and gains the
+// transparent ones 1.0-1.6 % (c2g 18.72 -> 18.53, glassbunny 14.78 -> 14.54): RZ_SHADE_NOINLINE 2 = the transparent kernels only.
+#ifndef RZ_SHADE_NOINLINE
+#define RZ_SHADE_NOINLINE 2
+#endif
+struct ShadeOut { v3 term; int ok; };
+template <bool GLASS>
+static __device__ __attribute__((noinline)) ShadeOut shade_term_call(const DevLight* lights, const DevMaterial* materials, float cx, float cy, float cz,
+                                                                     v3 hp, v3 normal, v3 lightDir, float maxDist, float vis, int li, int hmat) {
+    ShadeOut o;
+    o.term = mk3(0.0f, 0.0f, 0.0f);
+    o.ok = shade_term<GLASS>(lights, materials, mk3(cx, cy, cz), hp, normal, lightDir, maxDist, vis, li, hmat, o.term) ? 1 : 0;
+    return o;
+}
+// The light P.li is visible with P.vis: add its term.
+template <bool GLASS>
+__device__ __forceinline__ void shade_light(const KParams& K, Path& P) {
+    if (RZ_SHADE_NOINLINE == 1 || (RZ_SHADE_NOINLINE == 2 && GLASS)) {
+        const ShadeOut o = shade_term_call<GLASS>(K.lights, K.materials, K.camPos[0], K.camPos[1], K.camPos[2], P.hp, P.hn, P.d, P.maxDist, P.vis, P.li, P.hmat);
+        if (o.ok) P.lacc = P.lacc + o.term;
+    } else {
+        v3 term;
+        if (shade_term<GLASS>(K.lights, K.materials, mk3(K.camPos[0], K.camPos[1], K.camPos[2]), P.hp, P.hn, P.d, P.maxDist, P.vis, P.li, P.hmat, term))
+            P.lacc = P.lacc + term;
     }
 }
 
