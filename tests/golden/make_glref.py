@@ -46,7 +46,8 @@ def scenes():
         R(160, 120, 1, fps=59.9, show_lights=True),
         R(160, 120, 1, fps=7.0, show_bvh=True, bvh_mode=0),
         R(160, 120, 1, fps=142.7, show_bvh=True, bvh_mode=1, selected_blas=2, selected_tri=100)]
-    yield "cornell", S.cornell_scene, [R(128, 128, 1, spp=4), R(128, 128, 2), R(97, 61, 5)]
+    yield "cornell", S.cornell_scene, [R(256, 256, 1, spp=4),            # BASELINE configs[0], exactly
+                                      R(128, 128, 2), R(97, 61, 5)]
     yield "bunny24_extras", (lambda: S.bunny_scene(n=24, extras=True)), [R(192, 108, 2, spp=2), R(192, 108, 5)]
     yield "instanced16", (lambda: S.instanced_scene(n=12, count=16)), [R(160, 90, 2), R(160, 90, 5)]
     for seed in (4, 6, 8, 19, 27, 30, 37, 39):
@@ -86,7 +87,10 @@ def main():
     from oracle.glref import glref
     assert glref.available(), "needs /root/reference and Mesa's swrast_dri.so (the build container)"
     total = 0
+    only = set(sys.argv[1:])             # make_glref.py [scene ...]: regenerate these fixtures alone
     for name, make, renders in scenes():
+        if only and name not in only:
+            continue
         sc = make()
         if renders is None:
             renders = [sc._fuzz_render]
@@ -106,6 +110,8 @@ def main():
         np.savez_compressed(path, **data)
         total += os.path.getsize(path)
         print(name, [(r["W"], r["H"], r["budget"], r["spp"]) for r in renders], os.path.getsize(path), "bytes")
+    if only and "math_table" not in only:
+        return
     x, y = math_table()
     t = glref.probe_math(x, y, 0)
     path = os.path.join(HERE, "glref_math_table.npz")

@@ -78,7 +78,9 @@ def compare(got, want, render, what, same_random_numbers):
            f"means {g.mean():.6f} vs {w.mean():.6f}")
     assert bit >= 0.25, msg
     if render["budget"] <= 2:
-        assert far <= 0.002 and d.max() <= 1e-3, msg         # (one silhouette pixel of fuzz37 sits at 2e-4)
+        # (knife edges: one silhouette pixel of fuzz37 sits at 2e-4; on the Cornell box at 256 x 256 one of a pixel's four samples
+        #  grazes the cube's edge and hits in one implementation, misses in the other: 0.19 on 1 pixel of 65 536)
+        assert (d > 1e-4).sum() <= max(2, 0.002 * d.size), msg
     elif same_random_numbers:
         assert far <= 0.03, msg                              # (fuzzdeep37: 8 samples down six-segment mirror chains, 2.2 %; the others <= 0.02 %)
         assert abs(g.mean() - w.mean()) <= 2e-3 * w.mean(), msg
