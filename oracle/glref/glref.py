@@ -23,6 +23,31 @@ def available():
     return os.path.exists(os.path.join(SHADER_DIR, "fragment_shader.glsl")) and os.path.exists(DRIVER)
 
 
+_USABLE = None
+
+
+def usable():
+    """available(), the harness builds, and Mesa hands out an OpenGL >= 4.3 core context to it (probed once per process).
+    Returns (True, GL string) or (False, reason): the live tests skip with the reason instead of failing on a box whose Mesa differs."""
+    global _USABLE
+    if _USABLE is None:
+        if not available():
+            _USABLE = (False, "RayZen's shaders / Mesa's swrast driver not present")
+        else:
+            try:
+                build()
+                with tempfile.TemporaryDirectory() as td:
+                    blob = os.path.join(td, "probe.blob")
+                    eye = np.eye(4, dtype=np.float32).reshape(16)
+                    write_blob(blob, {}, eye, eye, eye, eye, np.zeros(3, np.float32), 1, 1, 1, 0)
+                    p = subprocess.run([BINARY, blob, os.path.join(td, "o"), SHADER_DIR], env=dict(os.environ, GLREF_DRIVER=DRIVER, GLREF_PROBE="1"),
+                                       capture_output=True, text=True, timeout=120)
+                _USABLE = (p.returncode == 0, p.stderr.strip()[-300:])
+            except Exception as e:          # no gcc, no headers, a driver that will not load ...
+                _USABLE = (False, f"{type(e).__name__}: {e}"[:300])
+    return _USABLE
+
+
 def build(force=False):
     src = os.path.join(_HERE, "glref.c")
     if not force and os.path.exists(BINARY) and os.path.getmtime(BINARY) >= os.path.getmtime(src):

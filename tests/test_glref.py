@@ -173,8 +173,9 @@ def test_hip_matches_the_reference_shader(name, k):
 
 def _glref():
     from oracle.glref import glref
-    if not glref.available():
-        pytest.skip("RayZen's shaders / Mesa's swrast driver not present (GPU box)")
+    ok, why = glref.usable()
+    if not ok:
+        pytest.skip(f"RayZen's shader cannot be run here (the GPU box has neither the reference nor its Mesa): {why}")
     return glref
 
 
