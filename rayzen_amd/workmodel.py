@@ -32,9 +32,14 @@ LANE_PEAK = SIMDS * 32 * MAX_CLOCK_HZ       # VALU lane slots per second: every 
 
 RCP, DIV_MORE, SQRT = 3, 3, 5               # v_rcp + one Newton step | Markstein's correction on a shared reciprocal | v_sqrt + residual step
 NORMALIZE = 5 + SQRT + RCP + 3 * DIV_MORE   # dot, sqrt, one reciprocal, three quotients = 22
+# sin / cos / acos: the prices below were set for rounds 1-4's binary64 forms, counted in slots -- and remain a floor for round 5's
+# binary32 forms (rz_device_math.h, RZ_MATH_FLAVOUR 1), whose slot counts come out the same or higher: sin = |x|, scale, range
+# compare, cvt, select, +1 & ~1, cvt, 3 fma, z, the lane's polynomial (4-7), sign (3), two clamps = 20-23; sincos = 30; acos =
+# 3 x (mul + add), |x|, sign (2), 1 - |x|, sqrt (5), mul, two subtractions = 18, which is what ACOS is priced at (the binary64 form took
+# ~35).  tests/test_workmodel.py holds floor <= executed on every committed counter file either way.
 F64_SIN = 20                                # cvt, reduction by pi/2 (mul, rint, 3 fma, quadrant 3), z, one 6-term polynomial, 2 to finish, select, cvt
 F64_SINCOS = 30                             # ... both polynomials (11), two finishes, selects, two cvt
-F64_ACOS = 35                               # cvt, |x|, z (2), p (6 fma + mul), q (4 fma), p / q (~10), sqrt (~10, the |x| >= 0.5 branch), 3 to finish
+F64_ACOS = 18                               # (the cheaper of the two flavours: see above)
 RAND = 3 + F64_SIN + 1 + 2                  # dot, sine, x 43758.5453, fract (floor + sub) = 26
 
 SLOTS = {
