@@ -662,9 +662,10 @@ bool use_samples(const rz_ctx* c) { return (c->flags & RZ_FLAG_MEGAKERNEL) == 0;
 // The claim counter (word 0, zeroed per launch) and the backstop word (word RZ_ERRWORD, zeroed when made and when reported).
 int ensure_group_counter(rz_ctx* c) {
     if (c->dGroupCtr.p) return RZ_OK;
-    int rc = ensure(c, c->dGroupCtr, 256);
+    // (+ a row of 64 zeros at byte 512, read by every wave's ordered sums in place of a dark unit's light rows: rz_kernels.hip, zero_row)
+    int rc = ensure(c, c->dGroupCtr, 1024);
     if (rc != RZ_OK) return rc;
-    RZ_HIP(c, hipMemsetAsync(c->dGroupCtr.p, 0, 256, c->stream));
+    RZ_HIP(c, hipMemsetAsync(c->dGroupCtr.p, 0, 1024, c->stream));
     return RZ_OK;
 }
 
