@@ -9,7 +9,7 @@
  * path.  Its SHADER half (rz_oracle.c, rz_oracle_present.c) is PINNED against
  * the reference itself, run here: oracle/glref loads RayZen's own GLSL from
  * /root/reference and runs it on the OpenGL 4.5 implementation the image ships
- * (Mesa llvmpipe); tests/golden/glref_*.npz hold 35 of its frames + a table of
+ * (Mesa llvmpipe); tests/golden/glref_*.npz hold 26 of its frames + a table of
  * its sin / cos / acos, and tests/test_glref.py compares: pixel by pixel at any
  * budget with math flavour 1 (llvmpipe's three built-ins replayed bit for bit:
  * the default, and the product's), to rounding wherever no random number is
