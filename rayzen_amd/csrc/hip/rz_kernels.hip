@@ -234,6 +234,9 @@ __device__ __forceinline__ void tally_flush(const KParams& K, const Tally& c) {
 #ifndef RZ_GROUPS_PER_CLAIM
 #define RZ_GROUPS_PER_CLAIM 8
 #endif
+#ifndef RZ_GROUPS_PER_CLAIM_SMALL_SPP
+#define RZ_GROUPS_PER_CLAIM_SMALL_SPP 6     // (plan_render_samples: launches of several pixels per wave below 3/4 M groups)
+#endif
 // trace_spread is compiled into the SPREAD flavour of the group code only (COMPACT == 1 of rz_render_samples: launches of
 // several pixels per wave): merely present in the 64-spp transparent variant it cost 8 % (c2g 24.6 -> 26.9 ms: registers).
 #define RZ_SPREAD_ON(K) (SPREAD && (K).spreadTrace != 0)
@@ -1506,7 +1509,12 @@ SamplesPlan plan_render_samples(int spp, int nSlots, bool glass) {
     //     frame 5.87 against 6.15) and its tail is 0.3 ms; 12 and 16 units: 11.04 -> 11.10 / 11.27 ms;
     //  * 16 units from 4 M units on (C3: 256 spp at 1080p; C5: 128 spp at 4K): more pixels per claim, so more paths to compact
     //     and more lanes in the ordered sums, and the tail no longer shows: C3 44.7 -> 43.0 ms, C5 118.2 -> 115.6.
-    const int claimUnits = units >= (4ll << 20) ? RZ_CLAIM_UNITS_LARGE : (units >= (3ll << 18) ? RZ_GROUPS_PER_CLAIM : std::max(1, RZ_GROUPS_PER_CLAIM / 2));
+    //  *  6 groups for launches of several pixels per wave under 3/4 M groups (C4: 16 spp at 1080p, 518 400 groups of four pixels;
+    //     round 5, profiles/r05_c4/claim_sweep_c4.log: 1 / 2 / 3 / 4 / 6 / 8 groups per claim -> 9.42 / 6.94 / 6.70 / 6.81 / 6.64 /
+    //     7.00 ms; RayZen's scene at 16 spp in its window: 1.89 / 1.41 / 1.37 / 1.40 / 1.41 / 1.45): a claim of four-pixel groups
+    //     parks more paths than one of single pixels, the pool fills sooner and the stratified claims (below) keep the tail short.
+    const int claimUnits = units >= (4ll << 20) ? RZ_CLAIM_UNITS_LARGE
+                         : (units >= (3ll << 18) ? RZ_GROUPS_PER_CLAIM : (spp < 64 ? RZ_GROUPS_PER_CLAIM_SMALL_SPP : std::max(1, RZ_GROUPS_PER_CLAIM / 2)));
     // Launches of several pixels per wave (spp < 64) take the persistent, compacting grid too (round 3): their late bounces
     // are where their time goes -- C4, 16 spp: rounds 4 and 5 of a path (bounces 2 and 3) ran 7 and 3 lanes wide and took 39 %
     // of the traversal's wave cycles (profiles/r03_c4_before/) -- and only a claim of several units has enough parked paths to
