@@ -59,17 +59,16 @@ def test_acos_accuracy_and_endpoints(flavour0):
 def test_rand_is_fract_sin_dot(flavour):
     """FS:188-190 with the flavour's sin: recompute in numpy float32, operation by operation."""
     L = rzo.lib()
-    L.rzo_set_math_flavour(flavour)
     rng = np.random.default_rng(2)
-    for _ in range(500):
-        x, y = np.float32(rng.uniform(0, 3000)), np.float32(rng.uniform(0, 3000))
-        d = np.float32(np.float32(x * np.float32(12.9898)) + np.float32(y * np.float32(78.233)))
-        s = np.float32(L.rzo_sin_f(float(d)))
-        p = np.float32(s * np.float32(43758.5453))
-        want = np.float32(p - np.floor(p))
-        got = np.float32(L.rzo_rand_f(float(x), float(y)))
-        assert got == want and 0.0 <= got < 1.0
-    L.rzo_set_math_flavour(1)
+    with rzo.math_flavour(flavour):         # (restores the process default -- the loaded product library's -- afterwards)
+        for _ in range(500):
+            x, y = np.float32(rng.uniform(0, 3000)), np.float32(rng.uniform(0, 3000))
+            d = np.float32(np.float32(x * np.float32(12.9898)) + np.float32(y * np.float32(78.233)))
+            s = np.float32(L.rzo_sin_f(float(d)))
+            p = np.float32(s * np.float32(43758.5453))
+            want = np.float32(p - np.floor(p))
+            got = np.float32(L.rzo_rand_f(float(x), float(y)))
+            assert got == want and 0.0 <= got < 1.0
 
 
 def test_rand_known_answers(flavour0):
