@@ -42,8 +42,9 @@ def main():
         sc = make_scene(c["scene"])
         img, cnt = oracle_render(sc, c["W"], c["H"], c["spp"], c["bounces"], want_counters=True)
         path = os.path.join(HERE, key + ".npz")
+        from oracle import rzo
         np.savez_compressed(path, accum=img, counters=np.array([cnt[k] for k in sorted(cnt)], np.uint64),
-                            counter_names=np.array(sorted(cnt)))
+                            counter_names=np.array(sorted(cnt)), math_flavour=np.array(rzo.lib().rzo_get_math_flavour()))
         print(key, img.shape, "mean", img[..., :3].mean(), os.path.getsize(path), "bytes")
 
 

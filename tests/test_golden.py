@@ -14,7 +14,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _load(key):
+    """The fixtures hold frames of ONE math flavour (rz_oracle_math.h; 1 = the product's default build): a suite that runs on the
+    other build of the library (-DRZ_MATH_FLAVOUR=0, RAYZEN_HIP_SO=...) skips them."""
+    from oracle import rzo
+    from helpers import sync_oracle_flavour
     z = np.load(os.path.join(HERE, "golden", key + ".npz"))
+    have = sync_oracle_flavour()
+    made = int(z["math_flavour"]) if "math_flavour" in z else 1
+    if have != made:
+        pytest.skip(f"golden fixtures hold math flavour {made}, the loaded library is flavour {have}")
     return z["accum"], dict(zip([str(n) for n in z["counter_names"]], [int(v) for v in z["counters"]]))
 
 
