@@ -245,3 +245,17 @@ def test_full_size_frames_against_the_live_shader(config):
     d = np.abs(got.astype(np.float64) - want).max(axis=-1)
     assert (d > 1e-4).sum() <= 1e-5 * d.size + 2, f"{config}: {(d > 1e-4).sum()} pixels of {d.size} beyond 1e-4, Linf {d.max():.3e}"
     assert (got.view(np.uint32) == want.view(np.uint32)).all(axis=-1).mean() > 0.4
+
+
+@pytest.mark.parametrize("num_lights", [0, 1, 2])
+def test_the_num_lights_uniform_against_the_live_shader(num_lights):
+    """`uniform int numLights` (FS:100; main.cpp:1368) may be smaller than the light buffer: the first numLights lights count."""
+    glref = _glref(same_llvmpipe=True)
+    sc = S.bunny_scene(n=24, extras=True)
+    img, _ = glref.render_scene(sc, 160, 90, 3, num_lights=num_lights, num_samples=2)
+    osc = oracle_scene(sc)
+    with rzo.math_flavour(1):
+        acc = rzo.render(osc, oracle_frame(sc, 160, 90, 2, 3, num_lights=num_lights), nthreads=8)
+    rgb, _ = rzo.present(osc, acc, sc.camera.view, sc.camera.proj, num_lights)
+    d = np.abs(img[..., :3].astype(np.float64) - rgb).max(axis=-1)
+    assert (d > 1e-4).sum() <= 2, f"numLights {num_lights}: {(d > 1e-4).sum()} pixels beyond 1e-4, Linf {d.max():.3e}"
