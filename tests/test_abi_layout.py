@@ -93,3 +93,19 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"rz_oracle|from oracle|import oracle|oracle/|rzo\b", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_the_library_says_which_built_ins_it_was_compiled_with():
+    """rz_math_flavour() (include/rayzen_hip.h; needs no GPU): the default build computes sin / cos / acos as the run of RayZen's own
+    shader did (flavour 1: tests/test_glref.py), and the oracle's default is the same one."""
+    from rayzen_amd import _lib
+    from oracle import rzo
+    import os
+    f = _lib.hip().rz_math_flavour()
+    assert f in (0, 1)
+    if not os.environ.get("RAYZEN_HIP_SO"):
+        assert f == 1
+    import subprocess, sys
+    out = subprocess.run([sys.executable, "-c", "from oracle import rzo; print(rzo.lib().rzo_get_math_flavour())"], capture_output=True, text=True,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env={k: v for k, v in os.environ.items() if k != "RZO_MATH_FLAVOUR"})
+    assert out.stdout.strip() == "1", out.stderr
