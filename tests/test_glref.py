@@ -259,3 +259,19 @@ def test_the_num_lights_uniform_against_the_live_shader(num_lights):
     rgb, _ = rzo.present(osc, acc, sc.camera.view, sc.camera.proj, num_lights)
     d = np.abs(img[..., :3].astype(np.float64) - rgb).max(axis=-1)
     assert (d > 1e-4).sum() <= 2, f"numLights {num_lights}: {(d > 1e-4).sum()} pixels beyond 1e-4, Linf {d.max():.3e}"
+
+
+@pytest.mark.parametrize("which", ["225 instances", "120k triangles"])
+def test_deep_trees_against_the_live_shader(which):
+    """A TLAS of 226 instances (depth 9: the list walk's skip positions, the shader's stack of TLAS nodes) and a BLAS of 120 000 triangles
+    (depth 18: the LDS stack window and its overflow) against RayZen's shader, budget 3, two samples."""
+    glref = _glref(same_llvmpipe=True)
+    if which.startswith("225"):
+        sc = S.instanced_scene(n=6, count=225)
+        W, H = 200, 112
+    else:
+        sc = S.stress_scene(n=100)
+        W, H = 160, 90
+    r = dict(W=W, H=H, budget=3, spp=2)
+    img, _ = glref.render_scene(sc, W, H, 3, num_samples=2)
+    compare(oracle_fragcolor(sc, r, flavour=1), np.ascontiguousarray(img[..., :3]), r, f"oracle[flavour 1] vs the live shader, {which}", True)
